@@ -1,0 +1,208 @@
+/*
+ * rip.h -- C-ABI of the MI355X-native RAW image pipeline (librip_hip.so).
+ *
+ * Drop-in boundary for raw_image_pipeline::RawImagePipeline (reference
+ * raw_image_pipeline/include/raw_image_pipeline/raw_image_pipeline.hpp:36-137, "hpp" below;
+ * implementation raw_image_pipeline/src/raw_image_pipeline/raw_image_pipeline.cpp, "cpp").
+ * One rip_pipeline == one reference RawImagePipeline object == one camera stream; like the
+ * reference it is not re-entrant (raw_image_pipeline_ros.cpp:14: one spinner thread per
+ * node).  Plain pointers and sizes only; no C++/torch/OpenCV types cross this boundary.
+ *
+ * Every per-frame stage runs as hand-written HIP kernels on gfx950; there is no CPU
+ * fallback.  Results follow the reference's CPU/OpenCV path (the parity target named by
+ * BASELINE.json), whatever `use_gpu` says.
+ *
+ * Errors: every function returns a rip_status; rip_last_error() gives the message.  The
+ * C++ facade (include/raw_image_pipeline/raw_image_pipeline.hpp) maps
+ * RIP_ERR_INVALID_ARGUMENT -> std::invalid_argument (reference debayer.cpp:76-78,
+ * white_balance.hpp:82-84), RIP_ERR_ASSERT -> the cv::Exception an OpenCV assert would
+ * have raised, RIP_ERR_IO -> YAML::Exception-class failures, the rest -> std::runtime_error.
+ */
+#ifndef RIP_H
+#define RIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rip_pipeline rip_pipeline;
+
+typedef enum {
+  RIP_OK = 0,
+  RIP_ERR_INVALID_ARGUMENT = 1, /* unsupported encoding / method / bad vector length */
+  RIP_ERR_ASSERT = 2,           /* input the reference's OpenCV call would assert on */
+  RIP_ERR_IO = 3,               /* malformed YAML / model file */
+  RIP_ERR_DEVICE = 4,           /* HIP runtime failure, no device */
+  RIP_ERR_CAPACITY = 5          /* caller's output buffer too small */
+} rip_status;
+
+/* Image taps kept per frame (reference keeps all three, unconditionally):
+ *   DEBAYERED  FlipModule::image_  (flip.cpp:60-62)   -> getDistDebayeredImage (cpp:222-224)
+ *   COLOR      UndistortionModule::dist_image_ (undistortion.cpp:247-249) -> getDistColorImage
+ *   PROCESSED  RawImagePipeline::image_ (hpp:174-177) -> getProcessedImage */
+enum { RIP_TAP_DEBAYERED = 1, RIP_TAP_COLOR = 2, RIP_TAP_PROCESSED = 4 };
+enum { RIP_IMAGE_DEBAYERED = 0, RIP_IMAGE_COLOR = 1, RIP_IMAGE_PROCESSED = 2, RIP_IMAGE_RECT_MASK = 3 };
+
+/* Device ordinal for a handle that only manages parameters (setters, getters, loaders, host-side
+ * tables and maps) -- used by the CPU-only tests.  Every frame call on it fails with
+ * RIP_ERR_DEVICE: there is no CPU execution path. */
+#define RIP_DEVICE_NONE (-1)
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+/* RawImagePipeline(bool use_gpu) / RawImagePipeline(use_gpu, params, calib, color_calib)
+ * (hpp:39-41, cpp:16-40).  NULL or "" paths: parameters take the loader defaults of
+ * cpp:44-165, no camera calibration, identity colour calibration *not available* (the
+ * reference bakes source-tree default paths in at compile time, cpp:9-12; this library
+ * ships no data files, so an empty params / colour-calibration path selects the VALUES of the
+ * reference's example files instead).  `device` is the HIP device ordinal. */
+rip_status rip_create(int device, int use_gpu, const char* params_path, const char* calibration_path,
+                      const char* color_calibration_path, rip_pipeline** out);
+/* RawImagePipeline(bool use_gpu) (hpp:39, cpp:16-21): the values of the reference's three example
+ * config files (params, 720x540 equidistant camera, colour matrix). */
+rip_status rip_create_default(int device, int use_gpu, rip_pipeline** out);
+void rip_destroy(rip_pipeline* p);
+/* Message of the last failure on this handle (p == NULL: of the last failed rip_create on
+ * this thread).  Valid until the next call on the handle. */
+const char* rip_last_error(const rip_pipeline* p);
+/* HIP stream (hipStream_t) all device work of this handle is enqueued on; default: the
+ * null stream.  The caller keeps ownership. */
+rip_status rip_set_stream(rip_pipeline* p, void* hip_stream);
+
+/* ---- frame API ----------------------------------------------------------------------- */
+/* bool apply(cv::Mat& image, std::string& encoding) (hpp:47, cpp:190-205) on host memory:
+ * uploads `image` (rows x cols x channels, `step` bytes per row), runs the chain, downloads
+ * into `out` (tightly packed, capacity in bytes) and rewrites the encoding ("bayer_*8" ->
+ * "bgr8").  The reference re-seats the caller's Mat; here the caller passes the output
+ * buffer, whose geometry is returned (90/270 flips swap rows/cols).  Synchronous. */
+rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step,
+                     const char* encoding, uint8_t* out, size_t out_capacity, int* out_rows, int* out_cols,
+                     int* out_channels, char encoding_out[32]);
+/* cv::Mat process(const cv::Mat&, std::string&) (hpp:50, cpp:182-188) is rip_apply with
+ * distinct in/out buffers -- which rip_apply already requires; the facade maps both. */
+
+/* Geometry/encoding rip_apply would produce for such an input (no device work). */
+rip_status rip_query_output(rip_pipeline* p, int rows, int cols, int channels, const char* encoding,
+                            int* out_rows, int* out_cols, int* out_channels, char encoding_out[32]);
+
+/* Device-resident, batched form of apply(): n_frames consecutive frames of THIS stream,
+ * already in HBM (frame f at d_in + f*in_frame_stride, rows of in_step bytes), results to
+ * d_out (frame stride out_frame_stride, row pitch out_step bytes; 0 = tightly packed).
+ * Asynchronous on the handle's stream; frames are processed in order (the ccc Kalman state
+ * advances frame by frame).  d_tap_debayered / d_tap_color (may be NULL) receive the
+ * per-frame taps, tightly packed, same frame count. */
+rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, size_t in_frame_stride,
+                            int n_frames, int rows, int cols, int channels, const char* encoding, void* d_out,
+                            size_t out_step, size_t out_frame_stride, void* d_tap_debayered, void* d_tap_color);
+
+/* Image getters (hpp:134-137, cpp:222-236): copy of the tap of the most recent rip_apply
+ * frame.  RIP_IMAGE_RECT_MASK is always empty (rows = cols = 0): the reference never writes
+ * rect_mask_ (undistortion.cpp:150-152). */
+rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_capacity, int* rows, int* cols,
+                         int* channels);
+/* Which taps rip_apply materialises (default: all three, as the reference does). */
+rip_status rip_set_taps(rip_pipeline* p, int tap_mask);
+
+/* ---- loaders (hpp:53-56) ---------------------------------------------------------------- */
+rip_status rip_load_params(rip_pipeline* p, const char* file_path);             /* cpp:44-165 */
+rip_status rip_load_camera_calibration(rip_pipeline* p, const char* file_path); /* undistortion.cpp:157-195 */
+rip_status rip_load_color_calibration(rip_pipeline* p, const char* file_path);  /* color_calibration.cpp:52-76 */
+rip_status rip_init_undistortion(rip_pipeline* p);                              /* undistortion.cpp:197-238 */
+/* CCC model ("default.bin" layout: int32 w, int32 h, float32 filter[h*w], bias[h*w];
+ * convolutional_color_constancy.cpp:116-132).  The reference loads a file baked in at
+ * compile time; this library ships none, so method "ccc" needs one of these calls. */
+rip_status rip_load_ccc_model(rip_pipeline* p, const char* file_path);
+rip_status rip_set_ccc_model(rip_pipeline* p, int width, int height, const float* filter, const float* bias);
+/* Kalman measurement model of the ccc temporal filter.  Default (h=0, r=1) is what the
+ * pipeline's one-argument ConvolutionalColorConstancyWB constructor leaves behind
+ * (convolutional_color_constancy.cpp:43-46 replaces the configured filter by a default
+ * cv::KalmanFilter: H = 0); (h=1, r=10) is loadModel's configuration (:186-202). */
+rip_status rip_set_ccc_kalman_model(rip_pipeline* p, double h, double r);
+
+/* ---- other interfaces (hpp:59-61) -------------------------------------------------------- */
+rip_status rip_reset_white_balance_temporal_consistency(rip_pipeline* p); /* cpp:218-220 */
+rip_status rip_set_gpu(rip_pipeline* p, int use_gpu);                     /* cpp:210-212; recorded only */
+rip_status rip_set_debug(rip_pipeline* p, int debug);                     /* cpp:214-216; recorded only */
+
+/* ---- setters (hpp:66-104; cpp:241-383) ---------------------------------------------------- */
+rip_status rip_set_debayer(rip_pipeline* p, int enabled);                         /* hpp:66 */
+rip_status rip_set_debayer_encoding(rip_pipeline* p, const char* encoding);       /* hpp:67 */
+rip_status rip_set_flip(rip_pipeline* p, int enabled);                            /* hpp:69 */
+rip_status rip_set_flip_angle(rip_pipeline* p, int angle);                        /* hpp:70 */
+rip_status rip_set_white_balance(rip_pipeline* p, int enabled);                   /* hpp:72 */
+rip_status rip_set_white_balance_method(rip_pipeline* p, const char* method);     /* hpp:73 */
+rip_status rip_set_white_balance_percentile(rip_pipeline* p, double percentile);  /* hpp:74 */
+rip_status rip_set_white_balance_saturation_threshold(rip_pipeline* p, double bright_thr, double dark_thr); /* hpp:75 */
+rip_status rip_set_white_balance_temporal_consistency(rip_pipeline* p, int enabled); /* hpp:76 */
+rip_status rip_set_color_calibration(rip_pipeline* p, int enabled);               /* hpp:77 */
+rip_status rip_set_color_calibration_matrix(rip_pipeline* p, const double* m, int n); /* hpp:78, n == 9 */
+rip_status rip_set_color_calibration_bias(rip_pipeline* p, const double* b, int n);   /* hpp:79, n == 3 */
+rip_status rip_set_gamma_correction(rip_pipeline* p, int enabled);                /* hpp:83 */
+rip_status rip_set_gamma_correction_method(rip_pipeline* p, const char* method);  /* hpp:84 */
+rip_status rip_set_gamma_correction_k(rip_pipeline* p, double k);                 /* hpp:85 */
+rip_status rip_set_vignetting_correction(rip_pipeline* p, int enabled);           /* hpp:87 */
+rip_status rip_set_vignetting_correction_parameters(rip_pipeline* p, double scale, double a2, double a4); /* hpp:88 */
+rip_status rip_set_color_enhancer(rip_pipeline* p, int enabled);                  /* hpp:90 */
+/* The reference's setters are cross-wired (color_enhancer.cpp:23-33): "hue" scales the V
+ * channel and "value" scales H.  Reproduced, so a drop-in caller sees the same pixels. */
+rip_status rip_set_color_enhancer_hue_gain(rip_pipeline* p, double gain);         /* hpp:91 */
+rip_status rip_set_color_enhancer_saturation_gain(rip_pipeline* p, double gain);  /* hpp:92 */
+rip_status rip_set_color_enhancer_value_gain(rip_pipeline* p, double gain);       /* hpp:93 */
+rip_status rip_set_undistortion(rip_pipeline* p, int enabled);                    /* hpp:95 */
+rip_status rip_set_undistortion_image_size(rip_pipeline* p, int width, int height);     /* hpp:96 */
+rip_status rip_set_undistortion_new_image_size(rip_pipeline* p, int width, int height); /* hpp:97 */
+rip_status rip_set_undistortion_balance(rip_pipeline* p, double balance);         /* hpp:98 */
+rip_status rip_set_undistortion_fov_scale(rip_pipeline* p, double fov_scale);     /* hpp:99 */
+rip_status rip_set_undistortion_camera_matrix(rip_pipeline* p, const double* k, int n);            /* hpp:100, n >= 9 */
+rip_status rip_set_undistortion_distortion_coefficients(rip_pipeline* p, const double* d, int n);  /* hpp:101, n >= 4 */
+rip_status rip_set_undistortion_distortion_model(rip_pipeline* p, const char* model);              /* hpp:102 */
+rip_status rip_set_undistortion_rectification_matrix(rip_pipeline* p, const double* r, int n);     /* hpp:103, n >= 9 */
+rip_status rip_set_undistortion_projection_matrix(rip_pipeline* p, const double* pm, int n);       /* hpp:104, n >= 12 */
+
+/* ---- getters (hpp:80-81, 109-132; cpp:388-489) ---------------------------------------------- */
+int rip_is_debayer_enabled(const rip_pipeline* p);               /* hpp:109 */
+int rip_is_flip_enabled(const rip_pipeline* p);                  /* hpp:110 */
+int rip_is_white_balance_enabled(const rip_pipeline* p);         /* hpp:111 */
+int rip_is_color_calibration_enabled(const rip_pipeline* p);     /* hpp:112 */
+int rip_is_gamma_correction_enabled(const rip_pipeline* p);      /* hpp:113 */
+int rip_is_vignetting_correction_enabled(const rip_pipeline* p); /* hpp:114 */
+int rip_is_color_enhancer_enabled(const rip_pipeline* p);        /* hpp:115 */
+int rip_is_undistortion_enabled(const rip_pipeline* p);          /* hpp:116 */
+int rip_get_dist_image_height(const rip_pipeline* p);            /* hpp:118 */
+int rip_get_dist_image_width(const rip_pipeline* p);             /* hpp:119 */
+int rip_get_rect_image_height(const rip_pipeline* p);            /* hpp:126 */
+int rip_get_rect_image_width(const rip_pipeline* p);             /* hpp:127 */
+/* Strings are copied into out[capacity] (NUL-terminated). */
+rip_status rip_get_dist_distortion_model(const rip_pipeline* p, char* out, size_t capacity); /* hpp:120 */
+rip_status rip_get_rect_distortion_model(const rip_pipeline* p, char* out, size_t capacity); /* hpp:128 */
+/* Matrices are written row-major as float64, like the CV_64F Mats the reference returns:
+ * 3x3 -> out[9], 1x4 -> out[4], 3x4 -> out[12]; colour calibration 3x3 / 4x1 (cv::Scalar). */
+rip_status rip_get_color_calibration_matrix(const rip_pipeline* p, double out[9]);   /* hpp:80 */
+rip_status rip_get_color_calibration_bias(const rip_pipeline* p, double out[4]);     /* hpp:81 */
+rip_status rip_get_dist_camera_matrix(const rip_pipeline* p, double out[9]);          /* hpp:121 */
+rip_status rip_get_dist_distortion_coefficients(const rip_pipeline* p, double out[4]);/* hpp:122 */
+rip_status rip_get_dist_rectification_matrix(const rip_pipeline* p, double out[9]);   /* hpp:123 */
+rip_status rip_get_dist_projection_matrix(const rip_pipeline* p, double out[12]);     /* hpp:124 */
+rip_status rip_get_rect_camera_matrix(const rip_pipeline* p, double out[9]);          /* hpp:129 */
+rip_status rip_get_rect_distortion_coefficients(const rip_pipeline* p, double out[4]);/* hpp:130 */
+rip_status rip_get_rect_rectification_matrix(const rip_pipeline* p, double out[9]);   /* hpp:131 */
+rip_status rip_get_rect_projection_matrix(const rip_pipeline* p, double out[12]);     /* hpp:132 */
+
+/* ---- introspection used by tests / bench (no reference counterpart) --------------------------- */
+/* Host copy of the undistortion maps (float32, map_rows x map_cols each); NULL pointers
+ * just query the size. */
+rip_status rip_get_undistortion_maps(rip_pipeline* p, float* map_x, float* map_y, size_t capacity_floats,
+                                     int* map_rows, int* map_cols);
+/* Per-frame white-balance results of the most recent device batch (D2H, synchronises):
+ * for frame f, out[f*8 ..] = {gain_b, gain_g, gain_r, q8_b, q8_g, q8_r, uv_x, uv_y}. */
+rip_status rip_get_white_balance_info(rip_pipeline* p, float* out, int n_frames);
+/* Host-built tables the kernels use (same ids as oracle ripo_table, plus 8: gamma LUT). */
+int rip_get_table(rip_pipeline* p, int which, int32_t* out, int capacity);
+const char* rip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

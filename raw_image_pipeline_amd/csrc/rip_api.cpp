@@ -1,0 +1,1020 @@
+// rip_api.cpp -- implementation of the C-ABI declared in include/rip.h: one handle owns the
+// module parameters (rip_host.hpp), the device-resident constants and scratch, and enqueues the
+// kernels of rip_kernels.hip on the caller's HIP stream.  There is no CPU execution path.
+#include "../../include/rip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rip_host.hpp"
+#include "rip_kernels.hpp"
+
+namespace {
+
+struct InvalidArgument : std::invalid_argument {
+  using std::invalid_argument::invalid_argument;
+};
+struct AssertError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct DeviceError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct CapacityError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                                  \
+  do {                                                                                                   \
+    hipError_t err_ = (expr);                                                                            \
+    if (err_ != hipSuccess)                                                                              \
+      throw DeviceError(std::string(#expr) + " failed: " + hipGetErrorString(err_) + " (" + __FILE__ + \
+                        ":" + std::to_string(__LINE__) + ")");                                           \
+  } while (0)
+
+thread_local std::string g_create_error;
+
+// Grow-only device buffer
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  void reserve(size_t bytes) {
+    if (bytes <= cap) return;
+    if (ptr) HIP_CHECK(hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8;
+    HIP_CHECK(hipMalloc(&ptr, want));
+    cap = want;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(ptr);
+  }
+};
+
+struct HostImage {
+  std::vector<uint8_t> data;
+  int rows = 0, cols = 0, channels = 0;
+};
+
+int parse_bayer(const std::string& e, int& ry, int& rx) {
+  // position of the R sample in the 2x2 cell for the ROS pattern names (debayer.cpp:48-70)
+  if (e == "bayer_rggb8") { ry = 0; rx = 0; return 1; }
+  if (e == "bayer_grbg8") { ry = 0; rx = 1; return 1; }
+  if (e == "bayer_gbrg8") { ry = 1; rx = 0; return 1; }
+  if (e == "bayer_bggr8") { ry = 1; rx = 1; return 1; }
+  return 0;
+}
+bool is_bayer16(const std::string& e) {
+  return e == "bayer_bggr16" || e == "bayer_gbrg16" || e == "bayer_grbg16" || e == "bayer_rggb16";
+}
+
+// What one frame geometry/encoding turns into
+struct Plan {
+  int src_kind = rip::SRC_BGR, ry = 0, rx = 0;
+  int channels = 3;       // channels after the debayer stage
+  int flip_angle = 0;     // effective
+  int mid_rows = 0, mid_cols = 0;  // post-flip geometry (pointwise chain output)
+  int out_rows = 0, out_cols = 0;
+  bool remap = false;
+  int wb_mode = rip::WB_NONE;
+  int stage_bits = 0;
+  std::string encoding_out;
+};
+
+}  // namespace
+
+struct rip_pipeline {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  rip::Modules m;
+  mutable std::string last_error;
+  int tap_mask = RIP_TAP_DEBAYERED | RIP_TAP_COLOR | RIP_TAP_PROCESSED;
+
+  // constants on the device
+  rip::DevTables h_tabs;
+  DevBuf d_tabs;
+  bool tabs_dirty = true;
+  // undistortion maps (interleaved float2), built lazily
+  std::vector<float> h_map;
+  DevBuf d_map;
+  bool map_dirty = true, map_uploaded = false;
+  // vignetting constants per geometry
+  rip::VignetteConst vig;
+  int vig_rows = -1, vig_cols = -1;
+  bool vig_dirty = true;
+  // ccc
+  rip::CccModel ccc;
+  DevBuf d_filter_fft, d_bias_fft, d_accum, d_ccc_state, d_geom;
+  bool ccc_uploaded = false, ccc_state_init = false, ccc_reset_pending = false, ccc_cfg_dirty = true;
+  double kf_h = 0.0, kf_r = 1.0;
+  int geom_rows = -1, geom_cols = -1;
+  // per-batch scratch
+  DevBuf d_stats, d_wb, d_hist, d_work, d_rowbest, d_argmax, d_mid;
+  int last_batch_frames = 0;
+  // host-apply staging and last-frame taps
+  DevBuf d_in, d_out, d_tap_deb, d_tap_col;
+  int last_rows[3] = {0, 0, 0}, last_cols[3] = {0, 0, 0}, last_cn[3] = {0, 0, 0};
+  bool last_valid[3] = {false, false, false};
+  DevBuf* last_buf[3] = {nullptr, nullptr, nullptr};
+
+  ~rip_pipeline() {
+    if (device < 0) return;
+    (void)hipSetDevice(device);
+    for (DevBuf* b : {&d_tabs, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
+                      &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col})
+      b->release();
+  }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// undistortion bookkeeping: UndistortionModule::init() (undistortion.cpp:197-238) minus the map
+// generation, which is deferred until a frame (or rip_init_undistortion) needs it.
+// ------------------------------------------------------------------------------------------------
+void und_init(rip_pipeline* p) {
+  rip::Modules& m = p->m;
+  double newK[9];
+  rip::fisheye_estimate_new_camera_matrix(m.dist_K, m.dist_D, m.dist_w, m.dist_h, m.dist_R, m.balance, m.rect_w, m.rect_h,
+                                          m.fov_scale, newK);
+  std::memcpy(m.rect_K, newK, sizeof(newK));
+  for (int i = 0; i < 4; i++) m.rect_D[i] = 0;
+  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  std::memcpy(m.rect_R, eye, sizeof(eye));
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) m.rect_P[i * 4 + j] = m.rect_K[i * 3 + j];
+  p->map_dirty = true;
+}
+
+void ensure_host_maps(rip_pipeline* p) {
+  if (!p->map_dirty) return;
+  const rip::Modules& m = p->m;
+  if (m.dist_w <= 0 || m.dist_h <= 0) throw AssertError("undistortion: image size is not set");
+  p->h_map.resize((size_t)m.dist_w * m.dist_h * 2);
+  // maps have the *dist* image size even after setNewImageSize (undistortion.cpp:216)
+  rip::fisheye_init_undistort_rectify_map(m.dist_K, m.dist_D, m.dist_R, m.rect_K, m.dist_w, m.dist_h, p->h_map.data());
+  p->map_dirty = false;
+  p->map_uploaded = false;
+}
+
+void ensure_maps(rip_pipeline* p) {
+  ensure_host_maps(p);
+  if (p->map_uploaded) return;
+  p->d_map.reserve(p->h_map.size() * sizeof(float));
+  HIP_CHECK(hipMemcpyAsync(p->d_map.ptr, p->h_map.data(), p->h_map.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
+  HIP_CHECK(hipStreamSynchronize(p->stream));
+  p->map_uploaded = true;
+}
+
+void ensure_tables(rip_pipeline* p) {
+  if (!p->tabs_dirty) return;
+  rip::DevTables& t = p->h_tabs;
+  const rip::ColorTables& c = rip::color_tables();
+  rip::build_gamma_lut(p->m.gamma_k, t.gamma_lut);
+  for (int i = 0; i < 256; i++) t.lin_tab[i] = c.srgb_gamma[p->m.gamma_enabled ? t.gamma_lut[i] : i];
+  std::memcpy(t.cbrt_tab, c.cbrt, sizeof(t.cbrt_tab));
+  for (int i = 0; i < 256; i++) t.yf_tab[i] = (uint32_t)c.lab_to_yf[2 * i] | ((uint32_t)c.lab_to_yf[2 * i + 1] << 16);
+  for (int i = 0; i < 4096; i++) t.inv_gamma[i] = (uint8_t)std::min<int>(255, c.inv_gamma[i]);
+  std::memcpy(t.sdiv, c.sdiv, sizeof(t.sdiv));
+  std::memcpy(t.hdiv, c.hdiv180, sizeof(t.hdiv));
+  std::memcpy(t.lab_fwd, c.fwd, sizeof(t.lab_fwd));
+  std::memcpy(t.lab_inv, c.inv, sizeof(t.lab_inv));
+  std::vector<float> accum;
+  rip::ccc_build_scalar_tables(t.log_tab, accum, t.exp_neg_tab);
+  rip::fft256_twiddles(t.tw_re, t.tw_im);
+  p->d_tabs.reserve(sizeof(rip::DevTables));
+  HIP_CHECK(hipMemcpyAsync(p->d_tabs.ptr, &t, sizeof(t), hipMemcpyHostToDevice, p->stream));
+  if (!p->d_accum.ptr) {
+    p->d_accum.reserve(accum.size() * sizeof(float));
+    HIP_CHECK(hipMemcpyAsync(p->d_accum.ptr, accum.data(), accum.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(p->stream));  // host staging buffers go out of scope
+  p->tabs_dirty = false;
+}
+
+void ensure_vignette(rip_pipeline* p, int rows, int cols) {
+  if (!p->vig_dirty && p->vig_rows == rows && p->vig_cols == cols) return;
+  p->vig = rip::build_vignette_const(rows, cols, p->m.vig_scale, p->m.vig_a2, p->m.vig_a4);
+  p->vig_rows = rows;
+  p->vig_cols = cols;
+  p->vig_dirty = false;
+}
+
+void ensure_ccc(rip_pipeline* p, int rows, int cols) {
+  if (!p->ccc.loaded) {
+    const char* env = std::getenv("RIP_CCC_MODEL");
+    if (env && *env) {
+      if (!rip::ccc_load_model_file(p->ccc, env)) throw InvalidArgument(std::string("RIP_CCC_MODEL: cannot read ") + env);
+      p->ccc_uploaded = false;
+    } else {
+      throw InvalidArgument(
+          "white balance method [ccc] needs a model: call rip_load_ccc_model()/rip_set_ccc_model() or set RIP_CCC_MODEL "
+          "(the reference loads raw_image_pipeline_white_balance/model/default.bin)");
+    }
+  }
+  if (!p->ccc_uploaded) {
+    size_t bytes = 65536 * 2 * sizeof(float);
+    p->d_filter_fft.reserve(bytes);
+    p->d_bias_fft.reserve(bytes);
+    HIP_CHECK(hipMemcpyAsync(p->d_filter_fft.ptr, p->ccc.filter_fft.data(), bytes, hipMemcpyHostToDevice, p->stream));
+    HIP_CHECK(hipMemcpyAsync(p->d_bias_fft.ptr, p->ccc.bias_fft.data(), bytes, hipMemcpyHostToDevice, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->ccc_uploaded = true;
+  }
+  if (!p->ccc_state_init) {
+    rip::CccState s = {};
+    s.first_frame = 1;
+    s.uv_x = s.uv_y = 128;  // uv_pos_ = (height/2, width/2), :178
+    s.st_x = s.st_y = 128.f;
+    s.kf_h = (float)p->kf_h;
+    s.kf_r = (float)p->kf_r;
+    s.temporal = p->m.wb_temporal ? 1 : 0;
+    p->d_ccc_state.reserve(sizeof(s));
+    HIP_CHECK(hipMemcpyAsync(p->d_ccc_state.ptr, &s, sizeof(s), hipMemcpyHostToDevice, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->ccc_state_init = true;
+    p->ccc_reset_pending = false;
+    p->ccc_cfg_dirty = false;
+  }
+  if (p->ccc_reset_pending || p->ccc_cfg_dirty) {
+    // patch individual fields, stream-ordered, keeping the filter state
+    rip::CccState* d = p->d_ccc_state.as<rip::CccState>();
+    if (p->ccc_reset_pending) {
+      static const int one = 1;
+      HIP_CHECK(hipMemcpyAsync(&d->first_frame, &one, sizeof(int), hipMemcpyHostToDevice, p->stream));
+    }
+    float hr[2] = {(float)p->kf_h, (float)p->kf_r};
+    int temporal = p->m.wb_temporal ? 1 : 0;
+    HIP_CHECK(hipMemcpyAsync(&d->kf_h, hr, sizeof(hr), hipMemcpyHostToDevice, p->stream));
+    HIP_CHECK(hipMemcpyAsync(&d->temporal, &temporal, sizeof(int), hipMemcpyHostToDevice, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->ccc_reset_pending = false;
+    p->ccc_cfg_dirty = false;
+  }
+  if (p->geom_rows != rows || p->geom_cols != cols) {
+    // cv::resize(src, small, Size(360,270)) coefficient tables (imgproc/resize.cpp)
+    struct Geom {
+      int xofs[360];
+      short ialpha[720];
+      int yofs[540];
+      short ibeta[540];
+      int area_fast;
+    };
+    static_assert(sizeof(Geom) % 4 == 0, "geom");
+    std::vector<uint8_t> raw(sizeof(Geom));
+    Geom& g = *reinterpret_cast<Geom*>(raw.data());
+    double scale_x = (double)cols / 360, scale_y = (double)rows / 270;
+    int isx = (int)std::lrint(scale_x), isy = (int)std::lrint(scale_y);
+    g.area_fast = (std::fabs(scale_x - isx) < 2.220446049250313e-16 && std::fabs(scale_y - isy) < 2.220446049250313e-16 && isx == 2 && isy == 2) ? 1 : 0;
+    auto sat16 = [](int v) { return (short)std::min(32767, std::max(-32768, v)); };
+    for (int dx = 0; dx < 360; dx++) {
+      float fx = (float)((dx + 0.5) * scale_x - 0.5);
+      int sx = (int)std::floor(fx);
+      fx -= sx;
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= cols - 1) { fx = 0; sx = cols - 1; }
+      g.xofs[dx] = sx;
+      g.ialpha[2 * dx] = sat16((int)std::lrintf((1.f - fx) * 2048));
+      g.ialpha[2 * dx + 1] = sat16((int)std::lrintf(fx * 2048));
+    }
+    for (int dy = 0; dy < 270; dy++) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      int sy = (int)std::floor(fy);
+      fy -= sy;
+      g.ibeta[2 * dy] = sat16((int)std::lrintf((1.f - fy) * 2048));
+      g.ibeta[2 * dy + 1] = sat16((int)std::lrintf(fy * 2048));
+      g.yofs[2 * dy] = std::min(std::max(sy, 0), rows - 1);
+      g.yofs[2 * dy + 1] = std::min(std::max(sy + 1, 0), rows - 1);
+    }
+    p->d_geom.reserve(sizeof(Geom));
+    HIP_CHECK(hipMemcpyAsync(p->d_geom.ptr, raw.data(), sizeof(Geom), hipMemcpyHostToDevice, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->geom_rows = rows;
+    p->geom_cols = cols;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// planning: raw_image_pipeline.hpp:143-172 stage gating
+// ------------------------------------------------------------------------------------------------
+Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const std::string& encoding) {
+  const rip::Modules& m = p->m;
+  Plan pl;
+  if (rows < 1 || cols < 1) throw AssertError("empty image");
+  pl.encoding_out = encoding;
+  if (parse_bayer(encoding, pl.ry, pl.rx)) {
+    if (channels != 1) throw AssertError("cv::demosaicing: Bayer input must have one channel");
+    if (rows < 3 || cols < 3) throw AssertError("cv::demosaicing: image too small");
+    pl.src_kind = rip::SRC_BAYER;
+    pl.channels = 3;
+    pl.encoding_out = "bgr8";
+  } else if (is_bayer16(encoding)) {
+    throw InvalidArgument("Encoding [" + encoding + "] is a valid pattern but is not supported!");
+  } else if (encoding == "rgb8") {
+    if (channels != 3) throw AssertError("cvtColor(RGB2BGR): rgb8 input must have three channels");
+    pl.src_kind = rip::SRC_RGB;  // swapped to BGR; the encoding string stays "rgb8" (debayer.cpp:72-73)
+    pl.channels = 3;
+  } else if (channels == 3) {
+    pl.src_kind = rip::SRC_BGR;
+    pl.channels = 3;
+  } else if (channels == 1) {
+    pl.src_kind = rip::SRC_MONO;
+    pl.channels = 1;
+  } else {
+    throw InvalidArgument("images with " + std::to_string(channels) + " channels are not supported");
+  }
+  pl.flip_angle = (m.flip_enabled && (m.flip_angle == 90 || m.flip_angle == 180 || m.flip_angle == 270)) ? m.flip_angle : 0;
+  const bool swap = pl.flip_angle == 90 || pl.flip_angle == 270;
+  pl.mid_rows = swap ? cols : rows;
+  pl.mid_cols = swap ? rows : cols;
+  if (m.wb_enabled && pl.channels == 3) {
+    const std::string& w = m.wb_method;
+    if (w == "gray_world" || w == "grey_world")
+      pl.wb_mode = rip::WB_Q8;
+    else if (w == "ccc")
+      pl.wb_mode = rip::WB_FLOAT;
+    else if (w == "pca")
+      pl.wb_mode = rip::WB_PCA;
+    else if (w == "simple" || w == "learned")
+      throw InvalidArgument("White Balance method [" + w + "] (cv::xphoto) is not implemented by the MI355X pipeline; use 'gray_world', 'ccc' or 'pca'");
+    else
+      throw InvalidArgument("White Balance method [" + w + "] not supported. Supported algorithms: 'simple', 'gray_world', 'learned', 'ccc', 'pca'");
+  }
+  if (m.cc_enabled && pl.channels == 3 && m.cc_available) pl.stage_bits |= rip::ST_CC;
+  if (m.gamma_enabled) pl.stage_bits |= rip::ST_GAMMA;
+  if (m.vig_enabled) {
+    if (pl.channels != 3) throw AssertError("cvtColor(BGR2Lab): vignetting correction needs a 3-channel image");
+    pl.stage_bits |= rip::ST_VIG;
+  }
+  if (m.ce_enabled && pl.channels == 3) pl.stage_bits |= rip::ST_HSV;
+  pl.remap = m.und_enabled && m.und_available && m.dist_model != "none";
+  pl.out_rows = pl.remap ? m.dist_h : pl.mid_rows;
+  pl.out_cols = pl.remap ? m.dist_w : pl.mid_cols;
+  return pl;
+}
+
+// Enqueues the whole chain for n frames.  d_out rows of out_step bytes.  Taps may be null.
+void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_step, size_t in_frame_stride, int n, int rows,
+               int cols, uint8_t* d_out, size_t out_step, size_t out_frame_stride, uint8_t* d_tap_deb, uint8_t* d_tap_col) {
+  HIP_CHECK(hipSetDevice(p->device));
+  ensure_tables(p);
+  const size_t mid_pitch = (size_t)pl.mid_cols * pl.channels;
+  const size_t mid_frame = mid_pitch * pl.mid_rows;
+  if (out_step == 0) out_step = (size_t)pl.out_cols * pl.channels;
+  if (out_frame_stride == 0) out_frame_stride = out_step * pl.out_rows;
+
+  p->d_wb.reserve(sizeof(rip::FrameWb) * (size_t)n);
+  // ---- white-balance statistics ---------------------------------------------------------------
+  if (pl.wb_mode == rip::WB_Q8 || pl.wb_mode == rip::WB_PCA) {
+    p->d_stats.reserve(sizeof(rip::FrameStats) * (size_t)n);
+    HIP_CHECK(hipMemsetAsync(p->d_stats.ptr, 0, sizeof(rip::FrameStats) * (size_t)n, p->stream));
+    rip::StatsParams sp = {};
+    sp.src = d_in;
+    sp.src_step = in_step;
+    sp.src_frame_stride = in_frame_stride;
+    sp.rows = rows;
+    sp.cols = cols;
+    sp.src_kind = pl.src_kind;
+    sp.bayer_ry = pl.ry;
+    sp.bayer_rx = pl.rx;
+    sp.n_frames = n;
+    sp.mode = pl.wb_mode;
+    sp.thresh255 = (unsigned)(uint16_t)std::lrintf((float)p->m.wb_bright_thr * 255);
+    sp.stats = p->d_stats.as<rip::FrameStats>();
+    rip::launch_stats(sp, p->stream);
+    rip::launch_wb_finalize(pl.wb_mode, sp.stats, nullptr, nullptr, p->d_tabs.as<rip::DevTables>(), p->d_wb.as<rip::FrameWb>(), n,
+                            p->stream);
+  } else if (pl.wb_mode == rip::WB_FLOAT) {
+    ensure_ccc(p, pl.mid_rows, pl.mid_cols);
+    p->d_hist.reserve((size_t)n * 65536 * sizeof(unsigned));
+    p->d_work.reserve((size_t)n * 65536 * 2 * sizeof(float));
+    p->d_rowbest.reserve((size_t)n * 256 * 2 * sizeof(float));
+    p->d_argmax.reserve((size_t)n * 2 * sizeof(int));
+    HIP_CHECK(hipMemsetAsync(p->d_hist.ptr, 0, (size_t)n * 65536 * sizeof(unsigned), p->stream));
+    rip::CccParams cp = {};
+    cp.src = d_in;
+    cp.src_step = in_step;
+    cp.src_frame_stride = in_frame_stride;
+    cp.rows = rows;
+    cp.cols = cols;
+    cp.src_kind = pl.src_kind;
+    cp.bayer_ry = pl.ry;
+    cp.bayer_rx = pl.rx;
+    cp.flip_angle = pl.flip_angle;
+    cp.drows = pl.mid_rows;
+    cp.dcols = pl.mid_cols;
+    cp.n_frames = n;
+    const uint8_t* g = p->d_geom.as<uint8_t>();
+    cp.geom.xofs = reinterpret_cast<const int*>(g);
+    cp.geom.ialpha = reinterpret_cast<const short*>(g + 360 * 4);
+    cp.geom.yofs = reinterpret_cast<const int*>(g + 360 * 4 + 720 * 2);
+    cp.geom.ibeta = reinterpret_cast<const short*>(g + 360 * 4 + 720 * 2 + 540 * 4);
+    {
+      int af = 0;
+      double sx = (double)pl.mid_cols / 360, sy = (double)pl.mid_rows / 270;
+      af = (sx == 2.0 && sy == 2.0) ? 1 : 0;
+      cp.geom.area_fast = af;
+    }
+    // setSaturationThreshold(float, float): thresholds are held as float (:437-440); 255 * thr in float
+    cp.upper = 255 * (float)p->m.wb_bright_thr;
+    cp.lower = 255 * (float)p->m.wb_dark_thr;
+    cp.hist_counts = p->d_hist.as<unsigned>();
+    cp.accum_tab = p->d_accum.as<float>();
+    cp.work = p->d_work.as<float>();
+    cp.filter_fft = p->d_filter_fft.as<float>();
+    cp.bias_fft = p->d_bias_fft.as<float>();
+    cp.row_best = p->d_rowbest.as<float>();
+    cp.argmax = p->d_argmax.as<int>();
+    cp.tabs = p->d_tabs.as<rip::DevTables>();
+    rip::launch_ccc_estimate(cp, p->stream);
+    rip::launch_wb_finalize(rip::WB_FLOAT, nullptr, cp.argmax, p->d_ccc_state.as<rip::CccState>(), cp.tabs, p->d_wb.as<rip::FrameWb>(),
+                            n, p->stream);
+  }
+  p->last_batch_frames = n;
+
+  // ---- fused chain -----------------------------------------------------------------------------
+  uint8_t* chain_dst = d_out;
+  size_t chain_step = out_step, chain_stride = out_frame_stride;
+  if (pl.remap) {
+    ensure_maps(p);
+    if (d_tap_col) {  // the pre-undistortion image is an API output: write it once, gather from it
+      chain_dst = d_tap_col;
+    } else {
+      p->d_mid.reserve(mid_frame * (size_t)n);
+      chain_dst = p->d_mid.as<uint8_t>();
+    }
+    chain_step = mid_pitch;
+    chain_stride = mid_frame;
+  }
+  rip::ChainParams c = {};
+  c.src = d_in;
+  c.src_step = in_step;
+  c.src_frame_stride = in_frame_stride;
+  c.rows = rows;
+  c.cols = cols;
+  c.src_kind = pl.src_kind;
+  c.bayer_ry = pl.ry;
+  c.bayer_rx = pl.rx;
+  c.dst = chain_dst;
+  c.dst_step = chain_step;
+  c.dst_frame_stride = chain_stride;
+  c.drows = pl.mid_rows;
+  c.dcols = pl.mid_cols;
+  c.channels = pl.channels;
+  c.tap = d_tap_deb;
+  c.tap_frame_stride = mid_frame;
+  c.flip_angle = pl.flip_angle;
+  c.n_frames = n;
+  c.wb_mode = pl.wb_mode;
+  c.wb = p->d_wb.as<rip::FrameWb>();
+  c.stage_bits = pl.stage_bits;
+  for (int i = 0; i < 9; i++) c.cc_m[i] = p->m.cc_matrix[i];
+  for (int i = 0; i < 3; i++) c.cc_bias[i] = (float)p->m.cc_bias[i];
+  if (pl.stage_bits & rip::ST_VIG) {
+    ensure_vignette(p, pl.mid_rows, pl.mid_cols);
+    c.vig_a2 = p->vig.a2;
+    c.vig_a4 = p->vig.a4;
+    c.vig_inv_max = p->vig.inv_max;
+    c.vig_scale = p->vig.scale;
+    c.vig_has_max = p->vig.has_max;
+  }
+  // cv::Scalar(hue_gain_, saturation_gain_, value_gain_) on (H,S,V), color_enhancer.cpp:42
+  c.hsv_gain[0] = (float)p->m.ce_hue_gain;
+  c.hsv_gain[1] = (float)p->m.ce_saturation_gain;
+  c.hsv_gain[2] = (float)p->m.ce_value_gain;
+  c.tabs = p->d_tabs.as<rip::DevTables>();
+  rip::launch_chain(c, p->stream);
+  if (!pl.remap && d_tap_col) {
+    // pre-undistortion copy == final image when no remap follows
+    for (int f = 0; f < n; f++)
+      HIP_CHECK(hipMemcpy2DAsync(d_tap_col + (size_t)f * mid_frame, mid_pitch, d_out + (size_t)f * out_frame_stride, out_step, mid_pitch,
+                                 (size_t)pl.mid_rows, hipMemcpyDeviceToDevice, p->stream));
+  }
+  // ---- remap -----------------------------------------------------------------------------------
+  if (pl.remap) {
+    rip::RemapParams r = {};
+    r.src = chain_dst;
+    r.src_step = mid_pitch;
+    r.src_frame_stride = mid_frame;
+    r.rows = pl.mid_rows;
+    r.cols = pl.mid_cols;
+    r.channels = pl.channels;
+    r.map_xy = p->d_map.as<float>();
+    r.dst = d_out;
+    r.dst_step = out_step;
+    r.dst_frame_stride = out_frame_stride;
+    r.drows = pl.out_rows;
+    r.dcols = pl.out_cols;
+    r.n_frames = n;
+    rip::launch_remap(r, p->stream);
+  }
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) throw DeviceError(std::string("kernel launch failed: ") + hipGetErrorString(le));
+}
+
+template <typename F>
+rip_status guarded(const rip_pipeline* p, F&& fn) {
+  try {
+    fn();
+    return RIP_OK;
+  } catch (const InvalidArgument& e) {
+    if (p) p->last_error = e.what();
+    return RIP_ERR_INVALID_ARGUMENT;
+  } catch (const std::invalid_argument& e) {
+    if (p) p->last_error = e.what();
+    return RIP_ERR_INVALID_ARGUMENT;
+  } catch (const AssertError& e) {
+    if (p) p->last_error = e.what();
+    return RIP_ERR_ASSERT;
+  } catch (const rip::YamlError& e) {
+    if (p) p->last_error = e.what();
+    return RIP_ERR_IO;
+  } catch (const CapacityError& e) {
+    if (p) p->last_error = e.what();
+    return RIP_ERR_CAPACITY;
+  } catch (const DeviceError& e) {
+    if (p) p->last_error = e.what();
+    return RIP_ERR_DEVICE;
+  } catch (const std::exception& e) {
+    if (p) p->last_error = e.what();
+    return RIP_ERR_DEVICE;
+  }
+}
+
+void need(const rip_pipeline* p) {
+  if (!p) throw InvalidArgument("null pipeline handle");
+}
+void need_device(const rip_pipeline* p) {
+  need(p);
+  if (p->device == RIP_DEVICE_NONE)
+    throw DeviceError("this handle was created with RIP_DEVICE_NONE (parameter handling only): frames can only be "
+                      "processed on a HIP device; there is no CPU execution path");
+}
+
+void copy_string(const std::string& s, char* out, size_t cap) {
+  if (!out || cap == 0) throw InvalidArgument("null output buffer");
+  if (s.size() + 1 > cap) throw CapacityError("string buffer too small");
+  std::memcpy(out, s.c_str(), s.size() + 1);
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* rip_version(void) { return "raw_image_pipeline_amd 0.1 (gfx950)"; }
+
+rip_status rip_create(int device, int use_gpu, const char* params_path, const char* calibration_path,
+                      const char* color_calibration_path, rip_pipeline** out) {
+  if (!out) {
+    g_create_error = "rip_create: out is null";
+    return RIP_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
+  rip_pipeline* p = nullptr;
+  try {
+    if (device != RIP_DEVICE_NONE) {
+      int count = 0;
+      hipError_t e = hipGetDeviceCount(&count);
+      if (e != hipSuccess || count <= 0)
+        throw DeviceError("no HIP device available: this library has no CPU execution path (hipGetDeviceCount: " +
+                          std::string(hipGetErrorString(e)) + ")");
+      if (device < 0 || device >= count) throw InvalidArgument("device ordinal out of range");
+      HIP_CHECK(hipSetDevice(device));
+    }
+    p = new rip_pipeline();
+    p->device = device;
+    p->m.use_gpu = use_gpu != 0;
+    // RawImagePipeline(use_gpu, params, calib, color_calib), raw_image_pipeline.cpp:23-40
+    if (!params_path || !*params_path) {
+      rip::apply_example_params(p->m);  // DEFAULT_PARAMS_PATH = config/pipeline_params_example.yaml
+    } else if (!rip::load_params_file(p->m, params_path)) {
+      std::fprintf(stderr, "Warning: parameters file doesn't exist\n");
+    }
+    if (calibration_path && *calibration_path) {
+      if (!rip::load_camera_calibration_file(p->m, calibration_path)) std::fprintf(stderr, "Warning: Calibration file doesn't exist\n");
+    }
+    if (!color_calibration_path || !*color_calibration_path) {
+      rip::apply_example_color_calibration(p->m);  // DEFAULT_COLOR_CALIBRATION_PATH
+    } else if (!rip::load_color_calibration_file(p->m, color_calibration_path)) {
+      std::fprintf(stderr, "Warning: Color calibration file doesn't exist\n");
+    }
+    und_init(p);
+    const char* env = std::getenv("RIP_CCC_MODEL");
+    if (env && *env) rip::ccc_load_model_file(p->ccc, env);
+    *out = p;
+    return RIP_OK;
+  } catch (const rip::YamlError& e) {
+    g_create_error = e.what();
+    delete p;
+    return RIP_ERR_IO;
+  } catch (const std::invalid_argument& e) {
+    g_create_error = e.what();
+    delete p;
+    return RIP_ERR_INVALID_ARGUMENT;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    delete p;
+    return RIP_ERR_DEVICE;
+  }
+}
+
+rip_status rip_create_default(int device, int use_gpu, rip_pipeline** out) {
+  // RawImagePipeline(bool use_gpu), raw_image_pipeline.cpp:16-21: example params, example camera
+  // calibration and example colour calibration
+  rip_status st = rip_create(device, use_gpu, nullptr, nullptr, nullptr, out);
+  if (st != RIP_OK) return st;
+  rip::apply_example_camera_calibration((*out)->m);
+  und_init(*out);
+  return RIP_OK;
+}
+
+void rip_destroy(rip_pipeline* p) { delete p; }
+
+const char* rip_last_error(const rip_pipeline* p) { return p ? p->last_error.c_str() : g_create_error.c_str(); }
+
+rip_status rip_set_stream(rip_pipeline* p, void* s) {
+  return guarded(p, [&] {
+    need_device(p);
+    p->stream = static_cast<hipStream_t>(s);
+  });
+}
+
+rip_status rip_query_output(rip_pipeline* p, int rows, int cols, int channels, const char* encoding, int* out_rows,
+                            int* out_cols, int* out_channels, char encoding_out[32]) {
+  return guarded(p, [&] {
+    need(p);
+    if (!encoding) throw InvalidArgument("encoding is null");
+    Plan pl = make_plan(p, rows, cols, channels, encoding);
+    if (out_rows) *out_rows = pl.out_rows;
+    if (out_cols) *out_cols = pl.out_cols;
+    if (out_channels) *out_channels = pl.channels;
+    if (encoding_out) copy_string(pl.encoding_out, encoding_out, 32);
+  });
+}
+
+rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, size_t in_frame_stride, int n_frames, int rows,
+                            int cols, int channels, const char* encoding, void* d_out, size_t out_step,
+                            size_t out_frame_stride, void* d_tap_debayered, void* d_tap_color) {
+  return guarded(p, [&] {
+    need_device(p);
+    if (!d_in || !d_out || !encoding) throw InvalidArgument("null buffer or encoding");
+    if (n_frames < 0) throw InvalidArgument("negative frame count");
+    if (n_frames == 0) return;
+    Plan pl = make_plan(p, rows, cols, channels, encoding);
+    if (in_step == 0) in_step = (size_t)cols * channels;
+    if (in_frame_stride == 0) in_frame_stride = in_step * rows;
+    if (in_step < (size_t)cols * channels) throw InvalidArgument("input row pitch smaller than a row");
+    run_batch(p, pl, static_cast<const uint8_t*>(d_in), in_step, in_frame_stride, n_frames, rows, cols, static_cast<uint8_t*>(d_out),
+              out_step, out_frame_stride, static_cast<uint8_t*>(d_tap_debayered), static_cast<uint8_t*>(d_tap_color));
+  });
+}
+
+rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step, const char* encoding,
+                     uint8_t* out, size_t out_capacity, int* out_rows, int* out_cols, int* out_channels,
+                     char encoding_out[32]) {
+  return guarded(p, [&] {
+    need_device(p);
+    if (!image || !out || !encoding) throw InvalidArgument("null buffer or encoding");
+    Plan pl = make_plan(p, rows, cols, channels, encoding);
+    HIP_CHECK(hipSetDevice(p->device));
+    if (step == 0) step = (size_t)cols * channels;
+    const size_t in_pitch = ((size_t)cols * channels + 3) & ~(size_t)3;  // dword-aligned rows on the device
+    const size_t in_bytes = in_pitch * rows;
+    const size_t out_bytes = (size_t)pl.out_rows * pl.out_cols * pl.channels;
+    const size_t mid_bytes = (size_t)pl.mid_rows * pl.mid_cols * pl.channels;
+    if (out_capacity < out_bytes) throw CapacityError("output buffer too small: need " + std::to_string(out_bytes) + " bytes");
+    p->d_in.reserve(in_bytes);
+    p->d_out.reserve(out_bytes);
+    uint8_t* tap_deb = nullptr;
+    uint8_t* tap_col = nullptr;
+    if (p->tap_mask & RIP_TAP_DEBAYERED) {
+      p->d_tap_deb.reserve(mid_bytes);
+      tap_deb = p->d_tap_deb.as<uint8_t>();
+    }
+    if (p->tap_mask & RIP_TAP_COLOR) {
+      p->d_tap_col.reserve(mid_bytes);
+      tap_col = p->d_tap_col.as<uint8_t>();
+    }
+    HIP_CHECK(hipMemcpy2DAsync(p->d_in.ptr, in_pitch, image, step, (size_t)cols * channels, (size_t)rows, hipMemcpyHostToDevice, p->stream));
+    run_batch(p, pl, p->d_in.as<uint8_t>(), in_pitch, in_bytes, 1, rows, cols, p->d_out.as<uint8_t>(), 0, 0, tap_deb, tap_col);
+    HIP_CHECK(hipMemcpyAsync(out, p->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    for (int i = 0; i < 3; i++) p->last_valid[i] = false;
+    auto remember = [&](int which, DevBuf* buf, int r, int c, bool on) {
+      p->last_valid[which] = on;
+      p->last_buf[which] = buf;
+      p->last_rows[which] = r;
+      p->last_cols[which] = c;
+      p->last_cn[which] = pl.channels;
+    };
+    remember(RIP_IMAGE_DEBAYERED, &p->d_tap_deb, pl.mid_rows, pl.mid_cols, tap_deb != nullptr);
+    remember(RIP_IMAGE_COLOR, &p->d_tap_col, pl.mid_rows, pl.mid_cols, tap_col != nullptr);
+    remember(RIP_IMAGE_PROCESSED, &p->d_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0);
+    if (out_rows) *out_rows = pl.out_rows;
+    if (out_cols) *out_cols = pl.out_cols;
+    if (out_channels) *out_channels = pl.channels;
+    if (encoding_out) copy_string(pl.encoding_out, encoding_out, 32);
+  });
+}
+
+rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_capacity, int* rows, int* cols, int* channels) {
+  return guarded(p, [&] {
+    need(p);
+    if (which == RIP_IMAGE_RECT_MASK || which < 0 || which > 3 || !p->last_valid[which]) {
+      // rect_mask_ is never written by the reference; taps that were not kept are empty too
+      if (which < 0 || which > 3) throw InvalidArgument("unknown image id");
+      if (rows) *rows = 0;
+      if (cols) *cols = 0;
+      if (channels) *channels = 0;
+      return;
+    }
+    size_t bytes = (size_t)p->last_rows[which] * p->last_cols[which] * p->last_cn[which];
+    if (rows) *rows = p->last_rows[which];
+    if (cols) *cols = p->last_cols[which];
+    if (channels) *channels = p->last_cn[which];
+    if (!out) return;  // size query
+    if (out_capacity < bytes) throw CapacityError("image buffer too small");
+    need_device(p);
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipMemcpyAsync(out, p->last_buf[which]->ptr, bytes, hipMemcpyDeviceToHost, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+  });
+}
+
+rip_status rip_set_taps(rip_pipeline* p, int mask) {
+  return guarded(p, [&] {
+    need(p);
+    p->tap_mask = mask & 7;
+  });
+}
+
+// ---- loaders -----------------------------------------------------------------------------------
+rip_status rip_load_params(rip_pipeline* p, const char* path) {
+  return guarded(p, [&] {
+    need(p);
+    if (!path) throw InvalidArgument("path is null");
+    std::printf("Loading raw_image_pipeline params from file %s\n", path);
+    if (!rip::load_params_file(p->m, path)) std::printf("Warning: parameters file doesn't exist\n");
+    p->tabs_dirty = p->vig_dirty = p->ccc_cfg_dirty = true;
+    und_init(p);  // setBalance / setFovScale re-run init()
+  });
+}
+rip_status rip_load_camera_calibration(rip_pipeline* p, const char* path) {
+  return guarded(p, [&] {
+    need(p);
+    if (!path) throw InvalidArgument("path is null");
+    std::printf("Loading camera calibration from file %s\n", path);
+    if (!rip::load_camera_calibration_file(p->m, path)) std::printf("Warning: Calibration file doesn't exist\n");
+    und_init(p);
+  });
+}
+rip_status rip_load_color_calibration(rip_pipeline* p, const char* path) {
+  return guarded(p, [&] {
+    need(p);
+    if (!path) throw InvalidArgument("path is null");
+    std::printf("Loading color calibration from file %s\n", path);
+    if (!rip::load_color_calibration_file(p->m, path)) std::printf("Warning: Color calibration file doesn't exist\n");
+  });
+}
+rip_status rip_init_undistortion(rip_pipeline* p) {
+  return guarded(p, [&] {
+    need(p);
+    und_init(p);
+    ensure_host_maps(p);
+    if (p->device != RIP_DEVICE_NONE) {
+      HIP_CHECK(hipSetDevice(p->device));
+      ensure_maps(p);
+    }
+  });
+}
+rip_status rip_load_ccc_model(rip_pipeline* p, const char* path) {
+  return guarded(p, [&] {
+    need(p);
+    if (!path) throw InvalidArgument("path is null");
+    if (!rip::ccc_load_model_file(p->ccc, path)) throw rip::YamlError(std::string("cannot read CCC model ") + path);
+    p->ccc_uploaded = false;
+  });
+}
+rip_status rip_set_ccc_model(rip_pipeline* p, int w, int h, const float* filter, const float* bias) {
+  return guarded(p, [&] {
+    need(p);
+    if (!filter || !bias) throw InvalidArgument("null model planes");
+    rip::ccc_build_model(p->ccc, w, h, filter, bias);
+    p->ccc_uploaded = false;
+  });
+}
+rip_status rip_set_ccc_kalman_model(rip_pipeline* p, double h, double r) {
+  return guarded(p, [&] {
+    need(p);
+    p->kf_h = h;
+    p->kf_r = r;
+    p->ccc_cfg_dirty = true;
+  });
+}
+
+rip_status rip_reset_white_balance_temporal_consistency(rip_pipeline* p) {
+  return guarded(p, [&] {
+    need(p);
+    if (p->m.wb_method == "ccc") p->ccc_reset_pending = true;  // white_balance.cpp:42-47
+  });
+}
+rip_status rip_set_gpu(rip_pipeline* p, int v) {
+  return guarded(p, [&] {
+    need(p);
+    p->m.use_gpu = v != 0;
+  });
+}
+rip_status rip_set_debug(rip_pipeline* p, int v) {
+  return guarded(p, [&] {
+    need(p);
+    p->m.debug = v != 0;
+  });
+}
+
+// ---- setters -----------------------------------------------------------------------------------
+#define RIP_SETTER(name, args, body)          \
+  rip_status name args {                      \
+    return guarded(p, [&] {                   \
+      need(p);                                \
+      body;                                   \
+    });                                       \
+  }
+
+RIP_SETTER(rip_set_debayer, (rip_pipeline * p, int v), p->m.debayer_enabled = v != 0)
+RIP_SETTER(rip_set_debayer_encoding, (rip_pipeline * p, const char* s), if (!s) throw InvalidArgument("null string"); p->m.debayer_encoding = s)
+RIP_SETTER(rip_set_flip, (rip_pipeline * p, int v), p->m.flip_enabled = v != 0)
+RIP_SETTER(rip_set_flip_angle, (rip_pipeline * p, int a), p->m.flip_angle = a)
+RIP_SETTER(rip_set_white_balance, (rip_pipeline * p, int v), p->m.wb_enabled = v != 0)
+RIP_SETTER(rip_set_white_balance_method, (rip_pipeline * p, const char* s), if (!s) throw InvalidArgument("null string"); p->m.wb_method = s)
+RIP_SETTER(rip_set_white_balance_percentile, (rip_pipeline * p, double v), p->m.wb_percentile = v)
+RIP_SETTER(rip_set_white_balance_saturation_threshold, (rip_pipeline * p, double b, double d), p->m.wb_bright_thr = b; p->m.wb_dark_thr = d)
+RIP_SETTER(rip_set_white_balance_temporal_consistency, (rip_pipeline * p, int v), p->m.wb_temporal = v != 0; p->ccc_cfg_dirty = true)
+RIP_SETTER(rip_set_color_calibration, (rip_pipeline * p, int v), p->m.cc_enabled = v != 0)
+RIP_SETTER(rip_set_color_calibration_matrix, (rip_pipeline * p, const double* v, int n),
+           if (!v || n != 9) throw InvalidArgument("color calibration matrix needs 9 values");
+           for (int i = 0; i < 9; i++) p->m.cc_matrix[i] = (float)v[i])  // Matx33d -> Matx33f, color_calibration.cpp:79
+RIP_SETTER(rip_set_color_calibration_bias, (rip_pipeline * p, const double* v, int n),
+           if (!v || n < 3) throw InvalidArgument("color calibration bias needs 3 values");  // vector::at throws
+           for (int i = 0; i < 3; i++) p->m.cc_bias[i] = v[i]; p->m.cc_bias[3] = 0)
+RIP_SETTER(rip_set_gamma_correction, (rip_pipeline * p, int v), p->m.gamma_enabled = v != 0; p->tabs_dirty = true)
+RIP_SETTER(rip_set_gamma_correction_method, (rip_pipeline * p, const char* s), if (!s) throw InvalidArgument("null string"); p->m.gamma_method = s)
+RIP_SETTER(rip_set_gamma_correction_k, (rip_pipeline * p, double k), p->m.gamma_k = k; p->tabs_dirty = true)
+RIP_SETTER(rip_set_vignetting_correction, (rip_pipeline * p, int v), p->m.vig_enabled = v != 0)
+RIP_SETTER(rip_set_vignetting_correction_parameters, (rip_pipeline * p, double s, double a2, double a4),
+           p->m.vig_scale = s; p->m.vig_a2 = a2; p->m.vig_a4 = a4; p->vig_dirty = true)
+RIP_SETTER(rip_set_color_enhancer, (rip_pipeline * p, int v), p->m.ce_enabled = v != 0)
+// cross-wired exactly as color_enhancer.cpp:23-33
+RIP_SETTER(rip_set_color_enhancer_hue_gain, (rip_pipeline * p, double g), p->m.ce_value_gain = g)
+RIP_SETTER(rip_set_color_enhancer_saturation_gain, (rip_pipeline * p, double g), p->m.ce_saturation_gain = g)
+RIP_SETTER(rip_set_color_enhancer_value_gain, (rip_pipeline * p, double g), p->m.ce_hue_gain = g)
+RIP_SETTER(rip_set_undistortion, (rip_pipeline * p, int v), p->m.und_enabled = v != 0)
+RIP_SETTER(rip_set_undistortion_image_size, (rip_pipeline * p, int w, int h), p->m.dist_w = p->m.rect_w = w; p->m.dist_h = p->m.rect_h = h; und_init(p))
+RIP_SETTER(rip_set_undistortion_new_image_size, (rip_pipeline * p, int w, int h), p->m.rect_w = w; p->m.rect_h = h; und_init(p))
+RIP_SETTER(rip_set_undistortion_balance, (rip_pipeline * p, double b), p->m.balance = b; und_init(p))
+RIP_SETTER(rip_set_undistortion_fov_scale, (rip_pipeline * p, double f), p->m.fov_scale = f; und_init(p))
+RIP_SETTER(rip_set_undistortion_camera_matrix, (rip_pipeline * p, const double* v, int n),
+           if (!v || n < 9) throw InvalidArgument("camera matrix needs 9 values");
+           for (int i = 0; i < 9; i++) p->m.dist_K[i] = p->m.rect_K[i] = v[i]; und_init(p))
+RIP_SETTER(rip_set_undistortion_distortion_coefficients, (rip_pipeline * p, const double* v, int n),
+           if (!v || n < 4) throw InvalidArgument("distortion coefficients need 4 values");
+           for (int i = 0; i < 4; i++) p->m.dist_D[i] = p->m.rect_D[i] = v[i]; und_init(p))
+RIP_SETTER(rip_set_undistortion_distortion_model, (rip_pipeline * p, const char* s), if (!s) throw InvalidArgument("null string");
+           p->m.dist_model = p->m.rect_model = s; und_init(p))
+RIP_SETTER(rip_set_undistortion_rectification_matrix, (rip_pipeline * p, const double* v, int n),
+           if (!v || n < 9) throw InvalidArgument("rectification matrix needs 9 values");
+           for (int i = 0; i < 9; i++) p->m.dist_R[i] = p->m.rect_R[i] = v[i]; und_init(p))
+RIP_SETTER(rip_set_undistortion_projection_matrix, (rip_pipeline * p, const double* v, int n),
+           if (!v || n < 12) throw InvalidArgument("projection matrix needs 12 values");
+           for (int i = 0; i < 12; i++) p->m.dist_P[i] = p->m.rect_P[i] = v[i]; und_init(p))
+
+// ---- getters -----------------------------------------------------------------------------------
+int rip_is_debayer_enabled(const rip_pipeline* p) { return p && p->m.debayer_enabled; }
+int rip_is_flip_enabled(const rip_pipeline* p) { return p && p->m.flip_enabled; }
+int rip_is_white_balance_enabled(const rip_pipeline* p) { return p && p->m.wb_enabled; }
+int rip_is_color_calibration_enabled(const rip_pipeline* p) { return p && p->m.cc_enabled; }
+int rip_is_gamma_correction_enabled(const rip_pipeline* p) { return p && p->m.gamma_enabled; }
+int rip_is_vignetting_correction_enabled(const rip_pipeline* p) { return p && p->m.vig_enabled; }
+int rip_is_color_enhancer_enabled(const rip_pipeline* p) { return p && p->m.ce_enabled; }
+int rip_is_undistortion_enabled(const rip_pipeline* p) { return p && p->m.und_enabled; }
+int rip_get_dist_image_height(const rip_pipeline* p) { return p ? p->m.dist_h : 0; }
+int rip_get_dist_image_width(const rip_pipeline* p) { return p ? p->m.dist_w : 0; }
+int rip_get_rect_image_height(const rip_pipeline* p) { return p ? p->m.rect_h : 0; }
+int rip_get_rect_image_width(const rip_pipeline* p) { return p ? p->m.rect_w : 0; }
+
+rip_status rip_get_dist_distortion_model(const rip_pipeline* p, char* out, size_t cap) {
+  return guarded(p, [&] {
+    need(p);
+    copy_string(p->m.und_available ? p->m.dist_model : std::string("none"), out, cap);  // undistortion.cpp:106-112
+  });
+}
+rip_status rip_get_rect_distortion_model(const rip_pipeline* p, char* out, size_t cap) {
+  return guarded(p, [&] {
+    need(p);
+    // undistortion.cpp:94-104: "none" once undistortion is enabled (the published image is rectified)
+    std::string s = "none";
+    if (p->m.und_available && !p->m.und_enabled) s = p->m.rect_model;
+    copy_string(s, out, cap);
+  });
+}
+
+#define RIP_GET_VEC(name, field, n)                              \
+  rip_status name(const rip_pipeline* p, double* out) {          \
+    return guarded(p, [&] {                                      \
+      need(p);                                                   \
+      if (!out) throw InvalidArgument("null output");            \
+      for (int i = 0; i < n; i++) out[i] = (double)p->m.field[i]; \
+    });                                                          \
+  }
+RIP_GET_VEC(rip_get_color_calibration_matrix, cc_matrix, 9)
+RIP_GET_VEC(rip_get_color_calibration_bias, cc_bias, 4)
+RIP_GET_VEC(rip_get_dist_camera_matrix, dist_K, 9)
+RIP_GET_VEC(rip_get_dist_distortion_coefficients, dist_D, 4)
+RIP_GET_VEC(rip_get_dist_rectification_matrix, dist_R, 9)
+RIP_GET_VEC(rip_get_dist_projection_matrix, dist_P, 12)
+RIP_GET_VEC(rip_get_rect_camera_matrix, rect_K, 9)
+RIP_GET_VEC(rip_get_rect_distortion_coefficients, rect_D, 4)
+RIP_GET_VEC(rip_get_rect_rectification_matrix, rect_R, 9)
+RIP_GET_VEC(rip_get_rect_projection_matrix, rect_P, 12)
+
+// ---- introspection -------------------------------------------------------------------------------
+rip_status rip_get_undistortion_maps(rip_pipeline* p, float* map_x, float* map_y, size_t cap, int* rows, int* cols) {
+  return guarded(p, [&] {
+    need(p);
+    if (rows) *rows = p->m.dist_h;
+    if (cols) *cols = p->m.dist_w;
+    if (!map_x || !map_y) return;
+    ensure_host_maps(p);
+    size_t n = (size_t)p->m.dist_w * p->m.dist_h;
+    if (cap < n) throw CapacityError("map buffers too small");
+    for (size_t i = 0; i < n; i++) {
+      map_x[i] = p->h_map[2 * i];
+      map_y[i] = p->h_map[2 * i + 1];
+    }
+  });
+}
+
+rip_status rip_get_white_balance_info(rip_pipeline* p, float* out, int n_frames) {
+  return guarded(p, [&] {
+    need(p);
+    if (!out || n_frames <= 0) throw InvalidArgument("bad arguments");
+    if (n_frames > p->last_batch_frames || !p->d_wb.ptr) throw InvalidArgument("no white-balance results for that many frames");
+    need_device(p);
+    HIP_CHECK(hipSetDevice(p->device));
+    std::vector<rip::FrameWb> h(n_frames);
+    HIP_CHECK(hipMemcpyAsync(h.data(), p->d_wb.ptr, sizeof(rip::FrameWb) * n_frames, hipMemcpyDeviceToHost, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    for (int f = 0; f < n_frames; f++) {
+      float* o = out + 8 * f;
+      o[0] = h[f].fg[0]; o[1] = h[f].fg[1]; o[2] = h[f].fg[2];
+      o[3] = (float)h[f].q8[0]; o[4] = (float)h[f].q8[1]; o[5] = (float)h[f].q8[2];
+      o[6] = (float)h[f].uv[0]; o[7] = (float)h[f].uv[1];
+    }
+  });
+}
+
+int rip_get_table(rip_pipeline* p, int which, int32_t* out, int cap) {
+  if (!p || !out) return -1;
+  const rip::ColorTables& c = rip::color_tables();
+  int n = 0;
+  auto put = [&](auto* tab, int cnt) {
+    n = cnt;
+    for (int i = 0; i < cnt && i < cap; i++) out[i] = (int32_t)tab[i];
+  };
+  switch (which) {
+    case 0: put(c.srgb_gamma, 256); break;
+    case 1: put(c.cbrt, 3072); break;
+    case 2: put(c.lab_to_yf, 512); break;
+    case 3: put(c.inv_gamma, 4096); break;
+    case 4: put(c.fwd, 9); break;
+    case 5: put(c.inv, 9); break;
+    case 6: put(c.sdiv, 256); break;
+    case 7: put(c.hdiv180, 256); break;
+    case 8: {
+      uint8_t lut[256];
+      rip::build_gamma_lut(p->m.gamma_k, lut);
+      put(lut, 256);
+      break;
+    }
+    default: return -1;
+  }
+  return n;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

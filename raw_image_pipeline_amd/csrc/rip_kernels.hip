@@ -1,0 +1,1156 @@
+// rip_kernels.hip -- gfx950 (MI355X) kernels of the RAW image chain.
+//
+// Stage semantics follow the reference's CPU/OpenCV path (file:line below are relative to the
+// reference tree):
+//   debayer   raw_image_pipeline/src/raw_image_pipeline/modules/debayer.cpp:45-79
+//   flip      .../modules/flip.cpp:37-58
+//   wb        .../modules/white_balance.cpp:59-64 (grey world), :73-136 (pca),
+//             raw_image_pipeline_white_balance/src/.../convolutional_color_constancy.cpp:91-113 (ccc)
+//   colour    .../modules/color_calibration.cpp:91-104
+//   gamma     .../modules/gamma_correction.cpp:35-60
+//   vignette  .../modules/vignetting_correction.cpp:32-93
+//   hsv       .../modules/color_enhancer.cpp:38-47
+//   remap     .../modules/undistortion.cpp:240-245
+//
+// Layout: everything is uint8 interleaved BGR in HBM.  The whole per-pixel chain
+// (debayer -> flip -> wb gains -> 3x3 -> gamma -> vignette -> hsv) is ONE kernel: 1 B/px read,
+// 3 B/px written; tables live in LDS; no intermediate image exists between those stages.
+// Compile with -ffp-contract=off: the float stages reproduce OpenCV's separate mul/add.
+#include "rip_kernels.hpp"
+
+#include <algorithm>
+#include <climits>
+
+namespace rip {
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sat_round_u8(float v) {
+  // saturate_cast<uchar>(float): round half to even, clamp (clamping first is equivalent)
+  v = __builtin_fminf(__builtin_fmaxf(v, 0.f), 255.f);
+  return (int)__builtin_rintf(v);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+struct SrcView {
+  const uint8_t* base;
+  size_t step;
+  int rows, cols, kind, ry, rx;
+};
+
+// Bilinear demosaic at one position with OpenCV's border rule (the interior formula evaluated
+// at the position clamped to [1, n-2]).
+__device__ __forceinline__ void debayer_at(const SrcView& s, int y, int x, int& b, int& g, int& r) {
+  int yc = clampi(y, 1, s.rows - 2), xc = clampi(x, 1, s.cols - 2);
+  const uint8_t* p = s.base + (size_t)yc * s.step + xc;
+  const ptrdiff_t st = (ptrdiff_t)s.step;
+  int dy = (yc - s.ry) & 1, dx = (xc - s.rx) & 1;  // (0,0): R site, (1,1): B site
+  int c = p[0];
+  if (dy != dx) {
+    int h = (p[-1] + p[1] + 1) >> 1;
+    int v = (p[-st] + p[st] + 1) >> 1;
+    g = c;
+    if (dy == 0) {
+      r = h;
+      b = v;
+    } else {
+      b = h;
+      r = v;
+    }
+  } else {
+    int x4 = (p[-1] + p[1] + p[-st] + p[st] + 2) >> 2;
+    int d4 = (p[-st - 1] + p[-st + 1] + p[st - 1] + p[st + 1] + 2) >> 2;
+    g = x4;
+    if (dy == 0) {
+      r = c;
+      b = d4;
+    } else {
+      b = c;
+      r = d4;
+    }
+  }
+}
+
+// Colour of the (pre-flip) source image at (y,x) for any supported input kind.
+__device__ __forceinline__ void fetch_src(const SrcView& s, int y, int x, int& b, int& g, int& r) {
+  if (s.kind == SRC_BAYER) {
+    debayer_at(s, y, x, b, g, r);
+  } else if (s.kind == SRC_MONO) {
+    b = g = r = s.base[(size_t)y * s.step + x];
+  } else {
+    const uint8_t* p = s.base + (size_t)y * s.step + (size_t)x * 3;
+    int c0 = p[0], c1 = p[1], c2 = p[2];
+    g = c1;
+    if (s.kind == SRC_RGB) {  // cvtColor(RGB2BGR), debayer.cpp:72-73
+      b = c2;
+      r = c0;
+    } else {
+      b = c0;
+      r = c2;
+    }
+  }
+}
+
+// destination (post-flip) -> source coordinates, flip.cpp:37-58
+__device__ __forceinline__ void unflip(int angle, int rows, int cols, int yd, int xd, int& ys, int& xs) {
+  if (angle == 180) {
+    ys = rows - 1 - yd;
+    xs = cols - 1 - xd;
+  } else if (angle == 90) {
+    ys = rows - 1 - xd;
+    xs = yd;
+  } else if (angle == 270) {
+    ys = xd;
+    xs = cols - 1 - yd;
+  } else {
+    ys = yd;
+    xs = xd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// table accessors: global (generic kernel) or LDS (fast kernel)
+// ------------------------------------------------------------------------------------------------
+struct GlobalTabs {
+  const DevTables* t;
+  __device__ __forceinline__ int gamma(int i) const { return t->gamma_lut[i]; }
+  __device__ __forceinline__ int lin(int i) const { return t->lin_tab[i]; }
+  __device__ __forceinline__ int cbrt(int i) const { return t->cbrt_tab[i]; }
+  __device__ __forceinline__ unsigned yf(int i) const { return t->yf_tab[i]; }
+  __device__ __forceinline__ int invg(int i) const { return t->inv_gamma[i]; }
+  __device__ __forceinline__ int sdiv(int i) const { return t->sdiv[i]; }
+  __device__ __forceinline__ int hdiv(int i) const { return t->hdiv[i]; }
+};
+
+template <bool ON, typename T, int N>
+struct LdsArr {
+  T v[N];
+};
+template <typename T, int N>
+struct LdsArr<false, T, N> {
+  T v[1];
+};
+
+template <int BITS>
+struct LdsTabs {
+  static constexpr bool kVig = (BITS & ST_VIG) != 0;
+  static constexpr bool kHsv = (BITS & ST_HSV) != 0;
+  // gamma bytes are only needed when the gamma result itself is consumed (not folded into lin_tab)
+  static constexpr bool kGamma = (BITS & ST_GAMMA) != 0 && !kVig;
+  LdsArr<kGamma, uint8_t, 256> gamma_;
+  LdsArr<kVig, uint16_t, 256> lin_;
+  LdsArr<kVig, uint16_t, 3072> cbrt_;
+  LdsArr<kVig, uint32_t, 256> yf_;
+  LdsArr<kVig, uint8_t, 4096> invg_;
+  LdsArr<kHsv, int32_t, 256> sdiv_;
+  LdsArr<kHsv, int32_t, 256> hdiv_;
+  __device__ __forceinline__ int gamma(int i) const { return gamma_.v[i]; }
+  __device__ __forceinline__ int lin(int i) const { return lin_.v[i]; }
+  __device__ __forceinline__ int cbrt(int i) const { return cbrt_.v[i]; }
+  __device__ __forceinline__ unsigned yf(int i) const { return yf_.v[i]; }
+  __device__ __forceinline__ int invg(int i) const { return invg_.v[i]; }
+  __device__ __forceinline__ int sdiv(int i) const { return sdiv_.v[i]; }
+  __device__ __forceinline__ int hdiv(int i) const { return hdiv_.v[i]; }
+
+  template <typename T, int N>
+  static __device__ __forceinline__ void copy(T (&dst)[N], const T* src) {
+    static_assert((N * sizeof(T)) % 4 == 0, "table size");
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    for (int i = threadIdx.x; i < (int)(N * sizeof(T) / 4); i += kBlock) d[i] = s[i];
+  }
+  __device__ __forceinline__ void load(const DevTables* t) {
+    if constexpr (kGamma) copy(gamma_.v, t->gamma_lut);
+    if constexpr (kVig) {
+      copy(lin_.v, t->lin_tab);
+      copy(cbrt_.v, t->cbrt_tab);
+      copy(yf_.v, t->yf_tab);
+      copy(invg_.v, t->inv_gamma);
+    }
+    if constexpr (kHsv) {
+      copy(sdiv_.v, t->sdiv);
+      copy(hdiv_.v, t->hdiv);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// per-pixel stages
+// ------------------------------------------------------------------------------------------------
+// white_balance.cpp: grey-world applyChannelGains (Q8, truncating), ccc cv::multiply (float,
+// round-half-even), pca quadratic on B and R.
+__device__ __forceinline__ void apply_wb(int mode, const FrameWb& w, int& b, int& g, int& r) {
+  if (mode == WB_Q8) {
+    b = (b * w.q8[0]) >> 8;
+    g = (g * w.q8[1]) >> 8;
+    r = (r * w.q8[2]) >> 8;
+  } else if (mode == WB_FLOAT) {
+    b = sat_round_u8((float)b * w.fg[0]);
+    g = sat_round_u8((float)g * w.fg[1]);
+    r = sat_round_u8((float)r * w.fg[2]);
+  } else if (mode == WB_PCA) {
+    float fb = (float)b, fr = (float)r;
+    float b2 = fb * fb, r2 = fr * fr;
+    float bp = b2 * w.pca[0] + fb * w.pca[1];
+    float rp = r2 * w.pca[2] + fr * w.pca[3];
+    bp = bp > 255.f ? 255.f : bp;  // THRESH_TRUNC
+    rp = rp > 255.f ? 255.f : rp;
+    b = sat_round_u8(bp);
+    r = sat_round_u8(rp);
+  }
+}
+
+// color_calibration.cpp:93-103: ((m0*B + m1*G) + m2*R) + bias in float32, no FMA
+__device__ __forceinline__ void apply_cc(const ChainParams& p, int& b, int& g, int& r) {
+  float fb = (float)b, fg = (float)g, fr = (float)r;
+  float o[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float t = fb * p.cc_m[c * 3] + fg * p.cc_m[c * 3 + 1] + fr * p.cc_m[c * 3 + 2];
+    o[c] = t + p.cc_bias[c];
+  }
+  b = sat_round_u8(o[0]);
+  g = sat_round_u8(o[1]);
+  r = sat_round_u8(o[2]);
+}
+
+// vignetting mask value at destination pixel (row, col): vignetting_correction.cpp:32-63
+__device__ __forceinline__ float vignette_mask(const ChainParams& p, int row, int col) {
+  int dx2 = 2 * col - p.dcols, dy2 = 2 * row - p.drows;
+  double s = (double)(dx2 * dx2 + dy2 * dy2) * 0.25;  // exact
+  double s2 = s * s;
+  double k = s * p.vig_a2 + s2 * p.vig_a4;
+  float m = (float)k;
+  if (p.vig_has_max) m = m * p.vig_inv_max;
+  m = m * p.vig_scale;
+  m = m + 1.0f;
+  return m;
+}
+
+// abToXZ_b[i - minABvalue] (OpenCV color_lab.cpp initLabTabs), evaluated arithmetically
+__device__ __forceinline__ int ab_to_xz(int i) {
+  if (i <= 3390) return i * 108 / 841 - 290;  // BASE*16/116*108/841 == 290
+  return (((i * i) >> 14) * i) >> 14;
+}
+
+// BGR -> 8-bit Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93; RGB2Lab_b /
+// Lab2RGBinteger).  `lin` already folds the gamma LUT when the gamma stage is on.
+template <typename Tabs>
+__device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs& tb, const int* fwd, const int* inv,
+                                               float mask, int& b, int& g, int& r) {
+  constexpr int kShift2 = 15;
+  int v0 = tb.lin(b), v1 = tb.lin(g), v2 = tb.lin(r);
+  int fX = tb.cbrt((v0 * fwd[0] + v1 * fwd[1] + v2 * fwd[2] + 2048) >> 12);
+  int fY = tb.cbrt((v0 * fwd[3] + v1 * fwd[4] + v2 * fwd[5] + 2048) >> 12);
+  int fZ = tb.cbrt((v0 * fwd[6] + v1 * fwd[7] + v2 * fwd[8] + 2048) >> 12);
+  const int Lscale = (116 * 255 + 50) / 100;
+  const int Lshift = -((16 * 255 * (1 << kShift2) + 50) / 100);
+  int L = (Lscale * fY + Lshift + (1 << 14)) >> kShift2;
+  int a = (500 * (fX - fY) + 128 * (1 << kShift2) + (1 << 14)) >> kShift2;
+  int bb = (200 * (fY - fZ) + 128 * (1 << kShift2) + (1 << 14)) >> kShift2;
+  L = clampi(L, 0, 255);
+  a = clampi(a, 0, 255);
+  bb = clampi(bb, 0, 255);
+  L = sat_round_u8((float)L * mask);
+  unsigned yf = tb.yf(L);
+  int y = (int)(yf & 0xffffu), ify = (int)(yf >> 16);
+  int adiv = ((5 * a * 53687 + (1 << 7)) >> 13) - 128 * 16384 / 500;
+  int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
+  int x = ab_to_xz(ify + adiv);
+  int z = ab_to_xz(ify - bdiv);
+  int bo = (inv[0] * x + inv[1] * y + inv[2] * z + (1 << 13)) >> 14;
+  int go = (inv[3] * x + inv[4] * y + inv[5] * z + (1 << 13)) >> 14;
+  int ro = (inv[6] * x + inv[7] * y + inv[8] * z + (1 << 13)) >> 14;
+  b = tb.invg(clampi(bo, 0, 4095));
+  g = tb.invg(clampi(go, 0, 4095));
+  r = tb.invg(clampi(ro, 0, 4095));
+}
+
+// color_enhancer.cpp:38-47: RGB2HSV_b (H in [0,180)), float gain with u8 saturation,
+// HSV2RGB_b (float)
+template <typename Tabs>
+__device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, int& b, int& g, int& r) {
+  int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+  int diff = v - vmin;
+  int s = (diff * tb.sdiv(v) + (1 << 11)) >> 12;
+  int h;
+  if (v == r)
+    h = g - b;
+  else if (v == g)
+    h = b - r + 2 * diff;
+  else
+    h = r - g + 4 * diff;
+  h = (h * tb.hdiv(diff) + (1 << 11)) >> 12;
+  h += h < 0 ? 180 : 0;
+  h = clampi(h, 0, 255);
+  int H = sat_round_u8((float)h * p.hsv_gain[0]);
+  int S = sat_round_u8((float)s * p.hsv_gain[1]);
+  int V = sat_round_u8((float)v * p.hsv_gain[2]);
+  float fh = (float)H, fs = (float)S * (1.f / 255.f), fv = (float)V * (1.f / 255.f);
+  float ob, og, orr;
+  if (fs == 0.f) {
+    ob = og = orr = fv;
+  } else {
+    fh = fh * (6.f / 180.f);
+    if (fh >= 6.f) fh = fh - 6.f;  // fmod(h, 6): h <= 255/30 < 12
+    int sector = (int)fh;          // floor, h >= 0
+    fh = fh - (float)sector;
+    if ((unsigned)sector >= 6u) {
+      sector = 0;
+      fh = 0.f;
+    }
+    float t0 = fv;
+    float t1 = fv * (1.f - fs);
+    float t2 = fv * (1.f - fs * fh);
+    float t3 = fv * (1.f - fs * (1.f - fh));
+    switch (sector) {
+      case 0: ob = t1; og = t3; orr = t0; break;
+      case 1: ob = t1; og = t0; orr = t2; break;
+      case 2: ob = t3; og = t0; orr = t1; break;
+      case 3: ob = t0; og = t2; orr = t1; break;
+      case 4: ob = t0; og = t1; orr = t3; break;
+      default: ob = t2; og = t1; orr = t0; break;
+    }
+  }
+  b = sat_round_u8(ob * 255.f);
+  g = sat_round_u8(og * 255.f);
+  r = sat_round_u8(orr * 255.f);
+}
+
+// The pointwise chain after flip.  BITS >= 0: compile-time stage set; BITS < 0: runtime.
+template <int BITS, typename Tabs>
+__device__ __forceinline__ void pointwise(const ChainParams& p, const FrameWb& w, const Tabs& tb, const int* fwd,
+                                          const int* inv, int yd, int xd, int& b, int& g, int& r) {
+  const int bits = BITS >= 0 ? BITS : p.stage_bits;
+  apply_wb(p.wb_mode, w, b, g, r);
+  if (bits & ST_CC) apply_cc(p, b, g, r);
+  if (bits & ST_VIG) {
+    // gamma folded into lin_tab by the host
+    apply_vignette(p, tb, fwd, inv, vignette_mask(p, yd, xd), b, g, r);
+  } else if (bits & ST_GAMMA) {
+    b = tb.gamma(b);
+    g = tb.gamma(g);
+    r = tb.gamma(r);
+  }
+  if (bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic chain kernel: one thread per destination pixel; any input kind, size, pitch, flip
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
+  const int frame = blockIdx.y;
+  const long long npix = (long long)p.drows * p.dcols;
+  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
+  GlobalTabs tb{p.tabs};
+  FrameWb w;
+  if (p.wb_mode != WB_NONE) w = p.wb[frame];
+  uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+  uint8_t* tap = p.tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
+    int yd = (int)(i / p.dcols), xd = (int)(i - (long long)yd * p.dcols);
+    int ys, xs;
+    unflip(p.flip_angle, p.rows, p.cols, yd, xd, ys, xs);
+    int b, g, r;
+    fetch_src(s, ys, xs, b, g, r);
+    if (p.channels == 1) {
+      // mono pass-through: only flip, gamma (cv::LUT is channel-agnostic) and remap apply
+      if (tap) tap[(size_t)yd * p.dcols + xd] = (uint8_t)g;
+      if (p.stage_bits & ST_GAMMA) g = p.tabs->gamma_lut[g];
+      dst[(size_t)yd * p.dst_step + xd] = (uint8_t)g;
+      continue;
+    }
+    if (tap) {
+      uint8_t* t = tap + ((size_t)yd * p.dcols + xd) * 3;
+      t[0] = (uint8_t)b;
+      t[1] = (uint8_t)g;
+      t[2] = (uint8_t)r;
+    }
+    pointwise<-1>(p, w, tb, p.tabs->lab_fwd, p.tabs->lab_inv, yd, xd, b, g, r);
+    uint8_t* o = dst + (size_t)yd * p.dst_step + (size_t)xd * 3;
+    o[0] = (uint8_t)b;
+    o[1] = (uint8_t)g;
+    o[2] = (uint8_t)r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast path: Bayer input, flip 0/180, cols % 4 == 0, rows % 2 == 0, dword-aligned pitches.
+// One work item = 4 px x 2 rows (two Bayer quads): a 6x4 sample window held in 12 registers
+// (three aligned dwords per row), 24 output bytes stored as two dwordx3.
+// ------------------------------------------------------------------------------------------------
+struct Window {
+  uint32_t w[4][3];  // rows y0-1 .. y0+2; dwords at x0-4, x0, x0+4
+  // sample at window row r, column offset i in [-1, 4] relative to x0
+  __device__ __forceinline__ int at(int r, int i) const {
+    const int idx = 4 + i;
+    return (int)((w[r][idx >> 2] >> (8 * (idx & 3))) & 0xffu);
+  }
+};
+
+__device__ __forceinline__ void load_window(const uint8_t* frame, size_t step, int rows, int cols, int y0, int x0,
+                                            Window& win) {
+  const int xl = x0 >= 4 ? x0 - 4 : x0;
+  const int xr = x0 + 4 < cols ? x0 + 4 : x0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int y = clampi(y0 - 1 + r, 0, rows - 1);
+    const uint8_t* row = frame + (size_t)y * step;
+    win.w[r][0] = *reinterpret_cast<const uint32_t*>(row + xl);
+    win.w[r][1] = *reinterpret_cast<const uint32_t*>(row + x0);
+    win.w[r][2] = *reinterpret_cast<const uint32_t*>(row + xr);
+  }
+}
+
+// px[ly][lx][c], c = 0:B 1:G 2:R.  RY/RX: position of the R sample in the 2x2 cell.
+template <int RY, int RX>
+__device__ __forceinline__ void debayer_tile(const Window& win, int (&px)[2][4][3]) {
+#pragma unroll
+  for (int ly = 0; ly < 2; ly++) {
+    const int cr = ly + 1;
+#pragma unroll
+    for (int lx = 0; lx < 4; lx++) {
+      const int dy = (ly ^ RY) & 1, dx = (lx ^ RX) & 1;
+      const int c = win.at(cr, lx);
+      if (dy != dx) {
+        int h = (win.at(cr, lx - 1) + win.at(cr, lx + 1) + 1) >> 1;
+        int v = (win.at(cr - 1, lx) + win.at(cr + 1, lx) + 1) >> 1;
+        px[ly][lx][1] = c;
+        px[ly][lx][dy == 0 ? 2 : 0] = h;
+        px[ly][lx][dy == 0 ? 0 : 2] = v;
+      } else {
+        int x4 = (win.at(cr, lx - 1) + win.at(cr, lx + 1) + win.at(cr - 1, lx) + win.at(cr + 1, lx) + 2) >> 2;
+        int d4 = (win.at(cr - 1, lx - 1) + win.at(cr - 1, lx + 1) + win.at(cr + 1, lx - 1) + win.at(cr + 1, lx + 1) + 2) >> 2;
+        px[ly][lx][1] = x4;
+        px[ly][lx][dy == 0 ? 2 : 0] = c;
+        px[ly][lx][dy == 0 ? 0 : 2] = d4;
+      }
+    }
+  }
+}
+
+// demosaic of the 4x2 tile at (y0, x0) including OpenCV's border replication
+__device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int rx, int y0, int x0, int rows, int cols,
+                                                 int (&px)[2][4][3]) {
+  switch (ry * 2 + rx) {
+    case 0: debayer_tile<0, 0>(win, px); break;
+    case 1: debayer_tile<0, 1>(win, px); break;
+    case 2: debayer_tile<1, 0>(win, px); break;
+    default: debayer_tile<1, 1>(win, px); break;
+  }
+  if (x0 == 0) {
+#pragma unroll
+    for (int ly = 0; ly < 2; ly++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) px[ly][0][c] = px[ly][1][c];
+  }
+  if (x0 + 4 == cols) {
+#pragma unroll
+    for (int ly = 0; ly < 2; ly++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) px[ly][3][c] = px[ly][2][c];
+  }
+  if (y0 == 0) {
+#pragma unroll
+    for (int lx = 0; lx < 4; lx++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) px[0][lx][c] = px[1][lx][c];
+  }
+  if (y0 + 2 == rows) {
+#pragma unroll
+    for (int lx = 0; lx < 4; lx++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) px[1][lx][c] = px[0][lx][c];
+  }
+}
+
+struct Pack3 {
+  uint32_t a, b, c;
+};
+// packs four BGR pixels (in the given order) into 12 bytes
+__device__ __forceinline__ Pack3 pack4(const int (&q)[4][3]) {
+  Pack3 o;
+  o.a = (uint32_t)q[0][0] | ((uint32_t)q[0][1] << 8) | ((uint32_t)q[0][2] << 16) | ((uint32_t)q[1][0] << 24);
+  o.b = (uint32_t)q[1][1] | ((uint32_t)q[1][2] << 8) | ((uint32_t)q[2][0] << 16) | ((uint32_t)q[2][1] << 24);
+  o.c = (uint32_t)q[2][2] | ((uint32_t)q[3][0] << 8) | ((uint32_t)q[3][1] << 16) | ((uint32_t)q[3][2] << 24);
+  return o;
+}
+__device__ __forceinline__ void store12(uint8_t* ptr, const Pack3& v) {
+  uint3 u;
+  u.x = v.a;
+  u.y = v.b;
+  u.z = v.c;
+  *reinterpret_cast<uint3*>(ptr) = u;
+}
+
+// item index -> (row pair, 4-px group) without an integer division per item
+struct ItemMap {
+  int groups_per_row;
+  float inv_groups;
+  __device__ __forceinline__ void split(int item, int& pair, int& grp) const {
+    int q = (int)((float)item * inv_groups);
+    int rem = item - q * groups_per_row;
+    if (rem < 0) {
+      q--;
+      rem += groups_per_row;
+    } else if (rem >= groups_per_row) {
+      q++;
+      rem -= groups_per_row;
+    }
+    pair = q;
+    grp = rem;
+  }
+};
+
+template <int BITS>
+__global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
+  __shared__ LdsTabs<BITS> tb;
+  __shared__ int s_fwd[9], s_inv[9];
+  tb.load(p.tabs);
+  if (threadIdx.x < 9) {
+    s_fwd[threadIdx.x] = p.tabs->lab_fwd[threadIdx.x];
+    s_inv[threadIdx.x] = p.tabs->lab_inv[threadIdx.x];
+  }
+  __syncthreads();
+  // Persistent workgroups: the LDS tables are loaded once and amortised over many chunks of
+  // kBlock items.  Block b runs on XCD b % 8 (observed dispatch order; speed only), so each
+  // XCD walks its own contiguous range of chunks and vertically adjacent row pairs -- which
+  // share two halo rows -- hit the same L2.
+  const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
+  const int total_chunks = chunks_per_frame * p.n_frames;
+  const int per_xcd = (total_chunks + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const bool flip180 = p.flip_angle == 180;
+  for (int ci = blockIdx.x >> 3; ci < per_xcd; ci += gridDim.x >> 3) {
+    const int chunk = xcd * per_xcd + ci;
+    if (chunk >= total_chunks) break;
+    const int frame = chunk / chunks_per_frame;
+    const int item = (chunk - frame * chunks_per_frame) * kBlock + threadIdx.x;
+    if (item >= items_per_frame) continue;
+    const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+    uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+    uint8_t* tap = p.tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr;
+    FrameWb w;
+    if (p.wb_mode != WB_NONE) w = p.wb[frame];
+    int pair, grp;
+    im.split(item, pair, grp);
+    const int y0 = pair * 2, x0 = grp * 4;
+    Window win;
+    load_window(src, p.src_step, p.rows, p.cols, y0, x0, win);
+    int px[2][4][3];
+    debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, px);
+#pragma unroll
+    for (int ly = 0; ly < 2; ly++) {
+      const int ys = y0 + ly;
+      const int yd = flip180 ? p.rows - 1 - ys : ys;
+      const int xbase = flip180 ? p.cols - 4 - x0 : x0;
+      int q[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int lx = flip180 ? 3 - k : k;  // k-th destination pixel of the group
+#pragma unroll
+        for (int c = 0; c < 3; c++) q[k][c] = flip180 ? px[ly][3 - k][c] : px[ly][k][c];
+        (void)lx;
+      }
+      if (tap) store12(tap + ((size_t)yd * p.dcols + xbase) * 3, pack4(q));
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        pointwise<BITS>(p, w, tb, s_fwd, s_inv, yd, xbase + k, q[k][0], q[k][1], q[k][2]);
+      store12(dst + (size_t)yd * p.dst_step + (size_t)xbase * 3, pack4(q));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics kernels (grey-world sums, pca sums/maxima): integer reductions, wave64 shuffles
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned wave_max(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down(v, off, 64));
+  return v;
+}
+
+struct StatAcc {
+  unsigned s[5];
+  unsigned m[3];
+};
+
+__device__ __forceinline__ void stat_add(const StatsParams& p, int b, int g, int r, StatAcc& a) {
+  if (p.mode == WB_Q8) {
+    // GrayworldWB calculateChannelSums: skip when (max-min)*255 > thresh255*max
+    unsigned mn = (unsigned)min(b, min(g, r)), mx = (unsigned)max(b, max(g, r));
+    if ((mx - mn) * 255u > p.thresh255 * mx) return;
+    a.s[0] += b;
+    a.s[1] += g;
+    a.s[2] += r;
+  } else {
+    a.s[0] += b;
+    a.s[1] += b * b;
+    a.s[2] += r;
+    a.s[3] += r * r;
+    a.s[4] += g;
+    a.m[0] = max(a.m[0], (unsigned)b);
+    a.m[1] = max(a.m[1], (unsigned)r);
+    a.m[2] = max(a.m[2], (unsigned)g);
+  }
+}
+
+__device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, FrameStats* out) {
+  __shared__ unsigned sh[8][kBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    unsigned v = wave_sum(a.s[k]);
+    if (lane == 0) sh[k][wid] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    unsigned v = wave_max(a.m[k]);
+    if (lane == 0) sh[5 + k][wid] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    unsigned long long t = 0;
+    for (int i = 0; i < kBlock / 64; i++) t += sh[threadIdx.x][i];
+    if (t) atomicAdd(&out->sum[threadIdx.x], t);
+  } else if (threadIdx.x < 8 && p.mode == WB_PCA) {
+    unsigned t = 0;
+    for (int i = 0; i < kBlock / 64; i++) t = max(t, sh[threadIdx.x][i]);
+    atomicMax(&out->mx[threadIdx.x - 5], t);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, ItemMap im, int items_per_frame) {
+  const int frame = blockIdx.y;
+  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  StatAcc a = {};
+  for (int item = blockIdx.x * kBlock + threadIdx.x; item < items_per_frame; item += gridDim.x * kBlock) {
+    int pair, grp;
+    im.split(item, pair, grp);
+    const int y0 = pair * 2, x0 = grp * 4;
+    Window win;
+    load_window(src, p.src_step, p.rows, p.cols, y0, x0, win);
+    int px[2][4][3];
+    debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, px);
+#pragma unroll
+    for (int ly = 0; ly < 2; ly++)
+#pragma unroll
+      for (int lx = 0; lx < 4; lx++) stat_add(p, px[ly][lx][0], px[ly][lx][1], px[ly][lx][2], a);
+  }
+  stat_flush(p, a, p.stats + frame);
+}
+
+__global__ __launch_bounds__(kBlock) void stats_generic_kernel(StatsParams p) {
+  const int frame = blockIdx.y;
+  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
+  const long long npix = (long long)p.rows * p.cols;
+  StatAcc a = {};
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
+    int y = (int)(i / p.cols), x = (int)(i - (long long)y * p.cols);
+    int b, g, r;
+    fetch_src(s, y, x, b, g, r);
+    stat_add(p, b, g, r, a);
+  }
+  stat_flush(p, a, p.stats + frame);
+}
+
+// ------------------------------------------------------------------------------------------------
+// white-balance finalisation: statistics -> per-frame gains, on the device (no host round trip)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void solve2(float m00, float m01, float m10, float m11, float g0, float g1, float& o0, float& o1) {
+  // Eigen::Matrix2f::inverse() * vec (white_balance.cpp:104-115)
+  float det = m00 * m11 - m01 * m10;
+  float invdet = 1.0f / det;
+  float i00 = m11 * invdet, i01 = -m01 * invdet, i10 = -m10 * invdet, i11 = m00 * invdet;
+  o0 = i00 * g0 + i01 * g1;
+  o1 = i10 * g0 + i11 * g1;
+}
+
+__global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* st,
+                                   const DevTables* tabs, FrameWb* out, int n_frames) {
+  if (mode == WB_FLOAT) {
+    // ccc: temporal filter is sequential over the frames of the stream
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    CccState s = *st;
+    for (int f = 0; f < n_frames; f++) {
+      s.uv_x = ccc_argmax[2 * f];
+      s.uv_y = ccc_argmax[2 * f + 1];
+      FrameWb w = {};
+      w.uv_raw[0] = s.uv_x;
+      w.uv_raw[1] = s.uv_y;
+      if (s.temporal) {
+        if (s.first_frame) {
+          s.first_frame = 0;
+          s.st_x = (float)s.uv_x;
+          s.st_y = (float)s.uv_y;
+        } else {
+          // cv::KalmanFilter(2,2,0) predict + correct with A = I, Q = I, H = h I, R = r I
+          float xs[2] = {s.st_x, s.st_y}, ps[2] = {s.p_x, s.p_y};
+          int z[2] = {s.uv_x, s.uv_y}, o[2];
+          for (int a = 0; a < 2; a++) {
+            float x_pre = xs[a];
+            float p_pre = ps[a] + 1.0f;
+            float t2 = s.kf_h * p_pre;
+            float t3 = t2 * s.kf_h + s.kf_r;
+            float k = t2 / t3;
+            float innov = (float)z[a] - s.kf_h * x_pre;
+            xs[a] = x_pre + k * innov;
+            ps[a] = p_pre - k * t2;
+            o[a] = (int)xs[a];
+          }
+          s.st_x = xs[0];
+          s.st_y = xs[1];
+          s.p_x = ps[0];
+          s.p_y = ps[1];
+          s.uv_x = o[0];
+          s.uv_y = o[1];
+        }
+      }
+      // computeGains (:342-381) with exp(-L) taken from the host-built table
+      int ux = clampi(s.uv_x, 0, 255), uy = clampi(s.uv_y, 0, 255);
+      float gain_r = 1.0f / tabs->exp_neg_tab[ux];
+      float gain_g = 1.0f;
+      float gain_b = 1.0f / tabs->exp_neg_tab[uy];
+      float factor = fminf(fminf(gain_r, gain_g), gain_b);
+      gain_r /= factor;
+      gain_g /= factor;
+      gain_b /= factor;
+      w.fg[0] = gain_b;
+      w.fg[1] = gain_g;
+      w.fg[2] = gain_r;
+      w.uv[0] = s.uv_x;
+      w.uv[1] = s.uv_y;
+      out[f] = w;
+    }
+    *st = s;
+    return;
+  }
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  FrameWb w = {};
+  const FrameStats& fs = stats[f];
+  if (mode == WB_Q8) {
+    // GrayworldWBImpl::balanceWhite + applyChannelGains
+    double sb = (double)fs.sum[0], sg = (double)fs.sum[1], sr = (double)fs.sum[2];
+    double max_sum = fmax(sb, fmax(sr, sg));
+    float gb = sb < 0.1 ? 0.f : (float)(max_sum / sb);
+    float gg = sg < 0.1 ? 0.f : (float)(max_sum / sg);
+    float gr = sr < 0.1 ? 0.f : (float)(max_sum / sr);
+    float gmax = fmaxf(gb, fmaxf(gg, gr));
+    if (gmax > 0) {
+      gb /= gmax;
+      gg /= gmax;
+      gr /= gmax;
+    }
+    w.q8[0] = (int)__builtin_rintf(gb * 256.f);
+    w.q8[1] = (int)__builtin_rintf(gg * 256.f);
+    w.q8[2] = (int)__builtin_rintf(gr * 256.f);
+    w.fg[0] = gb;
+    w.fg[1] = gg;
+    w.fg[2] = gr;
+  } else if (mode == WB_PCA) {
+    double s_b = (double)fs.sum[0], s_b2 = (double)fs.sum[1], s_r = (double)fs.sum[2], s_r2 = (double)fs.sum[3],
+           s_g = (double)fs.sum[4];
+    float mb = (float)fs.mx[0], mr = (float)fs.mx[1], mg = (float)fs.mx[2];
+    float mb2 = mb * mb, mr2 = mr * mr;
+    solve2((float)s_b2, (float)s_b, mb2, mb, (float)s_g, mg, w.pca[0], w.pca[1]);
+    solve2((float)s_r2, (float)s_r, mr2, mr, (float)s_g, mg, w.pca[2], w.pca[3]);
+  }
+  out[f] = w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ccc estimator: resize-sample -> log-chroma histogram -> FFT convolution -> argmax
+// ------------------------------------------------------------------------------------------------
+// colour of the post-flip image at (yd, xd)
+__device__ __forceinline__ void fetch_flipped(const SrcView& s, int angle, int yd, int xd, int& b, int& g, int& r) {
+  int ys, xs;
+  unflip(angle, s.rows, s.cols, yd, xd, ys, xs);
+  fetch_src(s, ys, xs, b, g, r);
+}
+
+__global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
+  const int frame = blockIdx.y;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= 360 * 270) return;
+  const int dy = i / 360, dx = i - dy * 360;
+  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
+  int sm[3];
+  if (p.geom.area_fast) {
+    int acc[3] = {2, 2, 2};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      int b, g, r;
+      fetch_flipped(s, p.flip_angle, 2 * dy + (t >> 1), 2 * dx + (t & 1), b, g, r);
+      acc[0] += b;
+      acc[1] += g;
+      acc[2] += r;
+    }
+    sm[0] = acc[0] >> 2;
+    sm[1] = acc[1] >> 2;
+    sm[2] = acc[2] >> 2;
+  } else {
+    // cv::resize INTER_LINEAR, 8U: Q11 coefficients, two-pass integer arithmetic
+    const int sx = p.geom.xofs[dx];
+    const int sx1 = sx + 1 < p.dcols ? sx + 1 : sx;
+    const int a0 = p.geom.ialpha[dx * 2], a1 = p.geom.ialpha[dx * 2 + 1];
+    const int y0 = p.geom.yofs[dy * 2], y1 = p.geom.yofs[dy * 2 + 1];
+    const int b0 = p.geom.ibeta[dy * 2], b1 = p.geom.ibeta[dy * 2 + 1];
+    int p00[3], p01[3], p10[3], p11[3];
+    fetch_flipped(s, p.flip_angle, y0, sx, p00[0], p00[1], p00[2]);
+    fetch_flipped(s, p.flip_angle, y0, sx1, p01[0], p01[1], p01[2]);
+    fetch_flipped(s, p.flip_angle, y1, sx, p10[0], p10[1], p10[2]);
+    fetch_flipped(s, p.flip_angle, y1, sx1, p11[0], p11[1], p11[2]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      int r0 = p00[c] * a0 + p01[c] * a1;
+      int r1 = p10[c] * a0 + p11[c] * a1;
+      sm[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    }
+  }
+  // calculateHistogramFeature (:210-271)
+  float fb = (float)sm[0], fg = (float)sm[1], fr = (float)sm[2];
+  float gray = fb * 0.114f + fg * 0.587f + fr * 0.299f;
+  bool ok = !(gray > p.upper) && (gray > p.lower);
+  if (sm[0] == 0 || sm[1] == 0 || sm[2] == 0) ok = false;  // log(0) = -inf is skipped
+  if (!ok) return;
+  const float bin_size = 1.0f / 64.0f, uv0 = -1.421875f;
+  float lb = p.tabs->log_tab[sm[0]], lg = p.tabs->log_tab[sm[1]], lr = p.tabs->log_tab[sm[2]];
+  int u = (int)roundf((lg - lr - uv0) / bin_size);
+  int v = (int)roundf((lg - lb - uv0) / bin_size);
+  u = clampi(u, 0, 255);
+  v = clampi(v, 0, 255);
+  atomicAdd(&p.hist_counts[(size_t)frame * 65536 + u * 256 + v], 1u);
+}
+
+// 256-point radix-2 DIT FFT in LDS, 128 threads, same butterfly order as the host reference
+// (rip_host.cpp host_fft256).  re/im hold bit-reversed input on entry.
+__device__ __forceinline__ unsigned bitrev8(unsigned x) { return __brev(x) >> 24; }
+
+__device__ __forceinline__ void fft256_lds(float* re, float* im, const float* twr, const float* twi, bool inverse) {
+  const int b = threadIdx.x;  // butterfly index 0..127
+  for (int len = 2; len <= 256; len <<= 1) {
+    const int half = len >> 1, tstep = 256 / len;
+    const int k = b & (half - 1), lo = (b / half) * len + k, hi = lo + half;
+    const float wr = twr[k * tstep], wi = inverse ? -twi[k * tstep] : twi[k * tstep];
+    const float xr = re[hi], xi = im[hi];
+    const float tr = wr * xr - wi * xi;
+    const float ti = wr * xi + wi * xr;
+    const float ur = re[lo], ui = im[lo];
+    __syncthreads();
+    re[lo] = ur + tr;
+    im[lo] = ui + ti;
+    re[hi] = ur - tr;
+    im[hi] = ui - ti;
+    __syncthreads();
+  }
+}
+
+// forward FFT of the histogram rows (counts -> float via the sequential-accumulation table)
+__global__ __launch_bounds__(128) void ccc_fft_rows_kernel(CccParams p) {
+  __shared__ float re[256], im[256], twr[128], twi[128];
+  const int row = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
+  twr[t] = p.tabs->tw_re[t];
+  twi[t] = p.tabs->tw_im[t];
+  const unsigned int* h = p.hist_counts + (size_t)frame * 65536 + row * 256;
+  for (int i = t; i < 256; i += 128) {
+    unsigned j = bitrev8((unsigned)i);
+    re[j] = p.accum_tab[h[i]];
+    im[j] = 0.f;
+  }
+  __syncthreads();
+  fft256_lds(re, im, twr, twi, false);
+  float2* out = reinterpret_cast<float2*>(p.work) + (size_t)frame * 65536 + row * 256;
+  for (int i = t; i < 256; i += 128) out[i] = make_float2(re[i], im[i]);
+}
+
+// forward FFT of a column, spectrum product + bias, inverse FFT of the column
+__global__ __launch_bounds__(128) void ccc_fft_cols_kernel(CccParams p) {
+  __shared__ float re[256], im[256], twr[128], twi[128], tr[256], ti[256];
+  const int col = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
+  twr[t] = p.tabs->tw_re[t];
+  twi[t] = p.tabs->tw_im[t];
+  float2* data = reinterpret_cast<float2*>(p.work) + (size_t)frame * 65536 + col;
+  for (int i = t; i < 256; i += 128) {
+    float2 v = data[(size_t)i * 256];
+    unsigned j = bitrev8((unsigned)i);
+    re[j] = v.x;
+    im[j] = v.y;
+  }
+  __syncthreads();
+  fft256_lds(re, im, twr, twi, false);
+  const float2* F = reinterpret_cast<const float2*>(p.filter_fft) + col;
+  const float2* B = reinterpret_cast<const float2*>(p.bias_fft) + col;
+  for (int i = t; i < 256; i += 128) {
+    float2 f = F[(size_t)i * 256], bb = B[(size_t)i * 256];
+    float ar = f.x, ai = f.y, br = re[i], bi = im[i];
+    float pr = ar * br - ai * bi;  // mulSpectrums, no conjugation
+    float pi = ar * bi + ai * br;
+    unsigned j = bitrev8((unsigned)i);
+    tr[j] = pr + bb.x;
+    ti[j] = pi + bb.y;
+  }
+  __syncthreads();
+  fft256_lds(tr, ti, twr, twi, true);
+  for (int i = t; i < 256; i += 128) data[(size_t)i * 256] = make_float2(tr[i], ti[i]);
+}
+
+// inverse FFT of the rows; per-row first maximum of the real part
+__global__ __launch_bounds__(128) void ccc_ifft_rows_kernel(CccParams p) {
+  __shared__ float re[256], im[256], twr[128], twi[128];
+  __shared__ float bv[128];
+  __shared__ int bi[128];
+  const int row = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
+  twr[t] = p.tabs->tw_re[t];
+  twi[t] = p.tabs->tw_im[t];
+  const float2* in = reinterpret_cast<const float2*>(p.work) + (size_t)frame * 65536 + row * 256;
+  for (int i = t; i < 256; i += 128) {
+    float2 v = in[i];
+    unsigned j = bitrev8((unsigned)i);
+    re[j] = v.x;
+    im[j] = v.y;
+  }
+  __syncthreads();
+  fft256_lds(re, im, twr, twi, true);
+  float v0 = re[t], v1 = re[t + 128];
+  bv[t] = v1 > v0 ? v1 : v0;
+  bi[t] = v1 > v0 ? t + 128 : t;
+  __syncthreads();
+  for (int off = 64; off > 0; off >>= 1) {
+    if (t < off) {
+      float ov = bv[t + off];
+      int oi = bi[t + off];
+      if (ov > bv[t] || (ov == bv[t] && oi < bi[t])) {
+        bv[t] = ov;
+        bi[t] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    p.row_best[((size_t)frame * 256 + row) * 2] = bv[0];
+    p.row_best[((size_t)frame * 256 + row) * 2 + 1] = (float)bi[0];
+  }
+}
+
+// cv::minMaxLoc: first maximum in row-major order -> Point(x = column, y = row)
+__global__ __launch_bounds__(256) void ccc_argmax_kernel(CccParams p) {
+  __shared__ float bv[256];
+  __shared__ int br[256];
+  const int frame = blockIdx.x, t = threadIdx.x;
+  bv[t] = p.row_best[((size_t)frame * 256 + t) * 2];
+  br[t] = t;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) {
+      float ov = bv[t + off];
+      int orow = br[t + off];
+      if (ov > bv[t] || (ov == bv[t] && orow < br[t])) {
+        bv[t] = ov;
+        br[t] = orow;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    int row = br[0];
+    p.argmax[2 * frame] = (int)p.row_best[((size_t)frame * 256 + row) * 2 + 1];
+    p.argmax[2 * frame + 1] = row;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// remap: cv::remap(INTER_LINEAR, BORDER_CONSTANT 0), undistortion.cpp:240-245
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int round_map(float v) {
+  float s = v * 32.f;
+  if (!(s > -2147483648.f && s < 2147483648.f)) return INT_MIN;  // cvRound of NaN/inf/out of range
+  return (int)__builtin_rintf(s);
+}
+
+template <int CN>
+__device__ __forceinline__ void remap_pixel(const uint8_t* src, size_t step, int rows, int cols, float mx, float my,
+                                            int (&out)[CN]) {
+  int sxq = round_map(mx), syq = round_map(my);
+  int sx = clampi(sxq >> 5, -32768, 32767), sy = clampi(syq >> 5, -32768, 32767);
+  int fx = sxq & 31, fy = syq & 31;
+  int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
+  if ((unsigned)sx < (unsigned)(cols - 1) && (unsigned)sy < (unsigned)(rows - 1)) {
+    const uint8_t* p0 = src + (size_t)sy * step + (size_t)sx * CN;
+    const uint8_t* p1 = p0 + step;
+#pragma unroll
+    for (int c = 0; c < CN; c++)
+      out[c] = clampi((p0[c] * w00 + p0[CN + c] * w01 + p1[c] * w10 + p1[CN + c] * w11 + (1 << 14)) >> 15, 0, 255);
+    return;
+  }
+  if (sx >= cols || sx + 1 < 0 || sy >= rows || sy + 1 < 0) {
+#pragma unroll
+    for (int c = 0; c < CN; c++) out[c] = 0;
+    return;
+  }
+  bool x0 = sx >= 0 && sx < cols, x1 = sx + 1 >= 0 && sx + 1 < cols;
+  bool y0 = sy >= 0 && sy < rows, y1 = sy + 1 >= 0 && sy + 1 < rows;
+#pragma unroll
+  for (int c = 0; c < CN; c++) {
+    int p00 = (x0 && y0) ? src[(size_t)sy * step + (size_t)sx * CN + c] : 0;
+    int p01 = (x1 && y0) ? src[(size_t)sy * step + (size_t)(sx + 1) * CN + c] : 0;
+    int p10 = (x0 && y1) ? src[(size_t)(sy + 1) * step + (size_t)sx * CN + c] : 0;
+    int p11 = (x1 && y1) ? src[(size_t)(sy + 1) * step + (size_t)(sx + 1) * CN + c] : 0;
+    out[c] = clampi((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15, 0, 255);
+  }
+}
+
+// 4 destination pixels per thread (CN == 3, dcols % 4 == 0, dword-aligned pitch)
+__global__ __launch_bounds__(kBlock) void remap_vec4_kernel(RemapParams p, ItemMap im, int items_per_frame) {
+  const int frame = blockIdx.y;
+  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+  for (int item = blockIdx.x * kBlock + threadIdx.x; item < items_per_frame; item += gridDim.x * kBlock) {
+    int yd, grp;
+    im.split(item, yd, grp);
+    const int xd = grp * 4;
+    const float4* m = reinterpret_cast<const float4*>(p.map_xy + ((size_t)yd * p.dcols + xd) * 2);
+    float4 m0 = m[0], m1 = m[1];
+    int q[4][3];
+    remap_pixel<3>(src, p.src_step, p.rows, p.cols, m0.x, m0.y, q[0]);
+    remap_pixel<3>(src, p.src_step, p.rows, p.cols, m0.z, m0.w, q[1]);
+    remap_pixel<3>(src, p.src_step, p.rows, p.cols, m1.x, m1.y, q[2]);
+    remap_pixel<3>(src, p.src_step, p.rows, p.cols, m1.z, m1.w, q[3]);
+    store12(dst + (size_t)yd * p.dst_step + (size_t)xd * 3, pack4(q));
+  }
+}
+
+template <int CN>
+__global__ __launch_bounds__(kBlock) void remap_generic_kernel(RemapParams p) {
+  const int frame = blockIdx.y;
+  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+  const long long npix = (long long)p.drows * p.dcols;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
+    int yd = (int)(i / p.dcols), xd = (int)(i - (long long)yd * p.dcols);
+    const float* m = p.map_xy + (size_t)i * 2;
+    int o[CN];
+    remap_pixel<CN>(src, p.src_step, p.rows, p.cols, m[0], m[1], o);
+    uint8_t* d = dst + (size_t)yd * p.dst_step + (size_t)xd * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) d[c] = (uint8_t)o[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+int grid_blocks_for(long long work_items, int max_blocks) {
+  long long b = (work_items + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+bool bayer_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, int rows, int cols, int kind) {
+  return kind == SRC_BAYER && cols % 4 == 0 && rows % 2 == 0 && rows >= 4 && cols >= 4 && step % 4 == 0 &&
+         frame_stride % 4 == 0 && aligned4(src);
+}
+
+template <int BITS>
+void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL(chain_fast_kernel<BITS>, grid, dim3(kBlock), 0, stream, p, im, items);
+}
+
+}  // namespace
+
+int chain_uses_fast_path(const ChainParams& p) {
+  return bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
+         (p.flip_angle == 0 || p.flip_angle == 180) && p.channels == 3 && p.dst_step % 4 == 0 &&
+         p.dst_frame_stride % 4 == 0 && aligned4(p.dst) && (!p.tap || (aligned4(p.tap) && p.tap_frame_stride % 4 == 0));
+}
+
+void launch_chain(const ChainParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  if (chain_uses_fast_path(p)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = (p.rows / 2) * (p.cols / 4);
+    const long long chunks = (long long)((items + kBlock - 1) / kBlock) * p.n_frames;
+    // persistent grid: at most 256 CUs x 8 workgroups, a multiple of 8 (one share per XCD)
+    int blocks = (int)std::min<long long>(2048, (chunks + 7) / 8 * 8);
+    dim3 grid(blocks);
+    switch (p.stage_bits & 15) {
+#define RIP_CASE(B) case B: launch_fast<B>(p, im, items, grid, stream); break;
+      RIP_CASE(0) RIP_CASE(1) RIP_CASE(2) RIP_CASE(3) RIP_CASE(4) RIP_CASE(5) RIP_CASE(6) RIP_CASE(7)
+      RIP_CASE(8) RIP_CASE(9) RIP_CASE(10) RIP_CASE(11) RIP_CASE(12) RIP_CASE(13) RIP_CASE(14) RIP_CASE(15)
+#undef RIP_CASE
+    }
+    return;
+  }
+  long long npix = (long long)p.drows * p.dcols;
+  dim3 grid(grid_blocks_for(npix, 2048), p.n_frames);
+  hipLaunchKernelGGL(chain_generic_kernel, grid, dim3(kBlock), 0, stream, p);
+}
+
+void launch_stats(const StatsParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  if (bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = (p.rows / 2) * (p.cols / 4);
+    // keep >= 1 block per 2^20 items so the 32-bit per-thread partial sums cannot overflow
+    int per_frame = grid_blocks_for(items, std::max(8, 2048 / std::max(1, std::min(p.n_frames, 16))));
+    per_frame = std::max(per_frame, (int)((items + (1 << 20) - 1) >> 20));
+    hipLaunchKernelGGL(stats_fast_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
+    return;
+  }
+  long long npix = (long long)p.rows * p.cols;
+  int blocks = std::max(grid_blocks_for(npix, 1024), (int)((npix + (1 << 22) - 1) >> 22));
+  hipLaunchKernelGGL(stats_generic_kernel, dim3(blocks, p.n_frames), dim3(kBlock), 0, stream, p);
+}
+
+void launch_ccc_estimate(const CccParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  hipLaunchKernelGGL(ccc_hist_kernel, dim3((360 * 270 + kBlock - 1) / kBlock, p.n_frames), dim3(kBlock), 0, stream, p);
+  hipLaunchKernelGGL(ccc_fft_rows_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
+  hipLaunchKernelGGL(ccc_fft_cols_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
+  hipLaunchKernelGGL(ccc_ifft_rows_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
+  hipLaunchKernelGGL(ccc_argmax_kernel, dim3(p.n_frames), dim3(256), 0, stream, p);
+}
+
+void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
+                        const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream) {
+  if (n_frames <= 0) return;
+  if (mode == WB_FLOAT) {
+    hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, stream, mode, stats, ccc_argmax, ccc_state, tabs, out, n_frames);
+  } else {
+    hipLaunchKernelGGL(wb_finalize_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, mode, stats, ccc_argmax,
+                       ccc_state, tabs, out, n_frames);
+  }
+}
+
+void launch_remap(const RemapParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  const bool vec = p.channels == 3 && p.dcols % 4 == 0 && p.dst_step % 4 == 0 && p.dst_frame_stride % 4 == 0 &&
+                   aligned4(p.dst) && (reinterpret_cast<uintptr_t>(p.map_xy) & 15u) == 0;
+  if (vec) {
+    ItemMap im{p.dcols / 4, 1.0f / (float)(p.dcols / 4)};
+    const int items = p.drows * (p.dcols / 4);
+    int per_frame = grid_blocks_for(items, std::max(8, 8192 / std::max(1, std::min(p.n_frames, 16))));
+    hipLaunchKernelGGL(remap_vec4_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
+    return;
+  }
+  long long npix = (long long)p.drows * p.dcols;
+  dim3 grid(grid_blocks_for(npix, 4096), p.n_frames);
+  if (p.channels == 3)
+    hipLaunchKernelGGL(remap_generic_kernel<3>, grid, dim3(kBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL(remap_generic_kernel<1>, grid, dim3(kBlock), 0, stream, p);
+}
+
+}  // namespace rip

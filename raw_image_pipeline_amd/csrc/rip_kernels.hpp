@@ -1,0 +1,150 @@
+// rip_kernels.hpp -- POD parameter blocks and launch entry points of the gfx950 kernels.
+// Everything here is plain data: the API layer (rip_api.cpp) fills the structs, the launchers
+// (rip_kernels.hip) enqueue on the caller's stream.  No allocation, no synchronisation.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace rip {
+
+enum SrcKind : int { SRC_BAYER = 0, SRC_BGR = 1, SRC_RGB = 2, SRC_MONO = 3 };
+enum WbMode : int { WB_NONE = 0, WB_Q8 = 1, WB_FLOAT = 2, WB_PCA = 3 };
+// Stage bits of the fused chain (compile-time specialisation key of the fast kernel)
+enum StageBits : int { ST_CC = 1, ST_GAMMA = 2, ST_VIG = 4, ST_HSV = 8 };
+
+// Constant tables in HBM (one blob per pipeline handle; copied to LDS by each workgroup).
+struct DevTables {
+  uint8_t gamma_lut[256];       // gamma_correction.cpp:35-43
+  uint16_t lin_tab[256];        // sRGBGammaTab_b[gamma_on ? gamma_lut[v] : v]
+  uint16_t cbrt_tab[3072];      // LabCbrtTab_b
+  uint32_t yf_tab[256];         // LabToYF_b: y | ify << 16
+  uint8_t inv_gamma[4096];      // sRGBInvGammaTab_b (values <= 255)
+  int32_t sdiv[256];            // RGB2HSV_b
+  int32_t hdiv[256];
+  int32_t lab_fwd[9];
+  int32_t lab_inv[9];
+  // ccc estimator
+  float log_tab[256];
+  float exp_neg_tab[256];
+  float tw_re[128], tw_im[128];
+};
+
+// Per-frame white-balance parameters, produced on the device by the statistics kernels.
+struct FrameWb {
+  int q8[3];      // grey-world Q8 gains (B,G,R)
+  float fg[3];    // float gains (B,G,R), ccc
+  float pca[4];   // b_c0, b_c1, r_c0, r_c1
+  int uv[2];      // ccc (x, y) used for the gains
+  int uv_raw[2];  // ccc argmax before temporal filtering
+  int pad[2];
+};
+
+// Raw per-frame statistics (zeroed before each batch).
+struct FrameStats {
+  unsigned long long sum[5];  // grey-world: B,G,R ; pca: B, B^2, R, R^2, G
+  unsigned int mx[3];         // pca: max B, R, G
+  unsigned int pad;
+};
+
+// Persistent ccc temporal state of one stream (convolutional_color_constancy.cpp:300-340).
+struct CccState {
+  int first_frame;
+  float st_x, st_y;  // statePost
+  float p_x, p_y;    // errorCovPost diagonal
+  int uv_x, uv_y;
+  float kf_h, kf_r;
+  int temporal;
+};
+
+struct ChainParams {
+  // source
+  const uint8_t* src;
+  size_t src_step, src_frame_stride;
+  int rows, cols;  // source geometry
+  int src_kind;    // SrcKind
+  int bayer_ry, bayer_rx;  // position of the R sample inside the 2x2 cell
+  // destination of the pointwise chain (post-flip geometry)
+  uint8_t* dst;
+  size_t dst_step, dst_frame_stride;
+  int drows, dcols;
+  int channels;  // 3, or 1 for mono pass-through
+  // optional post-flip, pre-WB tap (tightly packed rows), may be null
+  uint8_t* tap;
+  size_t tap_frame_stride;
+  int flip_angle;  // 0, 90, 180, 270
+  int n_frames;
+  // stages
+  int wb_mode;
+  const FrameWb* wb;  // [n_frames]
+  int stage_bits;     // StageBits
+  float cc_m[9], cc_bias[3];
+  double vig_a2, vig_a4;
+  float vig_inv_max, vig_scale;
+  int vig_has_max;
+  float hsv_gain[3];  // applied to H, S, V
+  const DevTables* tabs;
+};
+
+struct StatsParams {
+  const uint8_t* src;
+  size_t src_step, src_frame_stride;
+  int rows, cols, src_kind, bayer_ry, bayer_rx;
+  int n_frames;
+  int mode;  // WB_Q8: grey-world sums; WB_PCA: pca sums
+  unsigned thresh255;  // grey-world: cvRound(255 * thr)
+  FrameStats* stats;   // [n_frames], zeroed
+};
+
+struct CccGeom {
+  // cv::resize(..., Size(360,270)) tables for the current post-flip geometry
+  const int* xofs;       // [360]
+  const short* ialpha;   // [360][2]
+  const int* yofs;       // [270][2] clamped row indices
+  const short* ibeta;    // [270][2]
+  int area_fast;         // both scales exactly 2 -> 2x2 mean
+};
+
+struct CccParams {
+  const uint8_t* src;
+  size_t src_step, src_frame_stride;
+  int rows, cols, src_kind, bayer_ry, bayer_rx;
+  int flip_angle, drows, dcols;  // post-flip geometry the resize samples
+  int n_frames;
+  CccGeom geom;
+  float upper, lower;            // 255*bright_thr, 255*dark_thr
+  unsigned int* hist_counts;     // [n_frames][65536], zeroed
+  const float* accum_tab;        // [97201]
+  float* work;                   // [n_frames][65536] complex
+  const float* filter_fft;       // [65536] complex
+  const float* bias_fft;
+  float* row_best;               // [n_frames][256][2] (value, col)
+  int* argmax;                   // [n_frames][2] (x, y)
+  const DevTables* tabs;
+};
+
+struct RemapParams {
+  const uint8_t* src;
+  size_t src_step, src_frame_stride;
+  int rows, cols, channels;
+  const float* map_xy;  // interleaved (x,y), drows x dcols
+  uint8_t* dst;
+  size_t dst_step, dst_frame_stride;
+  int drows, dcols;
+  int n_frames;
+};
+
+// ---- launchers (asynchronous on `stream`) -------------------------------------------------------
+void launch_chain(const ChainParams& p, hipStream_t stream);
+void launch_stats(const StatsParams& p, hipStream_t stream);
+void launch_ccc_estimate(const CccParams& p, hipStream_t stream);
+// Turns raw statistics into FrameWb (grey-world / pca) or runs the ccc temporal filter + gains.
+void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
+                        const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream);
+void launch_remap(const RemapParams& p, hipStream_t stream);
+// Which code path launch_chain would pick (for tests / DESIGN.md): 1 fast, 0 generic.
+int chain_uses_fast_path(const ChainParams& p);
+
+}  // namespace rip

@@ -1,0 +1,459 @@
+"""Host-side mirror of the reference's Python binding (raw_image_pipeline_python/src/
+raw_image_pipeline_python.cpp:14-74: class ``RawImagePipeline``, 2 constructors, snake_case methods)
+implemented over the C-ABI of ``librip_hip.so`` (include/rip.h) with ctypes.
+
+All per-frame work runs in the HIP kernels of csrc/rip_kernels.hip; this module only marshals
+numpy / torch buffers.  It never falls back to a CPU implementation: a missing library or a
+missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librip_hip.so")
+
+RIP_OK, RIP_ERR_INVALID_ARGUMENT, RIP_ERR_ASSERT, RIP_ERR_IO, RIP_ERR_DEVICE, RIP_ERR_CAPACITY = range(6)
+TAP_DEBAYERED, TAP_COLOR, TAP_PROCESSED = 1, 2, 4
+IMAGE_DEBAYERED, IMAGE_COLOR, IMAGE_PROCESSED, IMAGE_RECT_MASK = 0, 1, 2, 3
+
+
+class RipError(RuntimeError):
+    """HIP/device failure (RIP_ERR_DEVICE, RIP_ERR_CAPACITY)."""
+
+
+class RipAssertError(RipError):
+    """Input the reference's OpenCV call would have asserted on (cv::Exception)."""
+
+
+class RipIOError(RipError, IOError):
+    """Malformed YAML / model file (YAML::Exception class of failures)."""
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads librip_hip.so.  Raises if it has not been built (``python -m raw_image_pipeline_amd.build``
+    or ``__graft_entry__.build()``): there is no other implementation to fall back to."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: build it with `python raw_image_pipeline_amd/build.py` "
+                           "(hipcc, gfx950). The pipeline has no CPU fallback." % path)
+    lib = C.CDLL(path)
+    lib.rip_last_error.restype = C.c_char_p
+    lib.rip_last_error.argtypes = [C.c_void_p]
+    lib.rip_version.restype = C.c_char_p
+    lib.rip_destroy.restype = None
+    lib.rip_destroy.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _as_doubles(values, n=None):
+    arr = (C.c_double * len(values))(*[float(v) for v in values])
+    return arr, len(values)
+
+
+class RawImagePipeline:
+    """Same surface as ``py_raw_image_pipeline.RawImagePipeline``.
+
+    ``RawImagePipeline(use_gpu)`` mirrors the one-argument constructor (example params, example
+    camera and colour calibration); ``RawImagePipeline(use_gpu, params_path, calibration_path,
+    color_calibration_path)`` the four-argument one.  ``use_gpu`` is recorded only: every stage
+    always runs on the MI355X and follows the reference's CPU/OpenCV arithmetic.
+    """
+
+    _ONE_ARG = object()
+
+    def __init__(self, use_gpu=False, params_path=_ONE_ARG, calibration_path="", color_calibration_path="",
+                 device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.last_encoding = None
+        if params_path is RawImagePipeline._ONE_ARG:
+            st = self._lib.rip_create_default(int(device), int(bool(use_gpu)), C.byref(self._h))
+        else:
+            st = self._lib.rip_create(int(device), int(bool(use_gpu)), (params_path or "").encode(),
+                                      (calibration_path or "").encode(), (color_calibration_path or "").encode(),
+                                      C.byref(self._h))
+        if st != RIP_OK:
+            msg = self._lib.rip_last_error(None).decode()
+            self._h = C.c_void_p()
+            self._raise(st, msg)
+        self.device = int(device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.rip_destroy(h)
+            self._h = C.c_void_p()
+
+    close = __del__
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    @staticmethod
+    def _raise(st, msg):
+        if st == RIP_ERR_INVALID_ARGUMENT:
+            raise ValueError(msg)  # std::invalid_argument
+        if st == RIP_ERR_ASSERT:
+            raise RipAssertError(msg)
+        if st == RIP_ERR_IO:
+            raise RipIOError(msg)
+        raise RipError(msg)
+
+    def _check(self, st):
+        if st != RIP_OK:
+            self._raise(st, self._lib.rip_last_error(self._h).decode())
+
+    def _call(self, name, *args):
+        self._check(getattr(self._lib, name)(self._h, *args))
+
+    def set_stream(self, stream):
+        """HIP stream handle (int / torch.cuda.Stream) the device work is enqueued on."""
+        handle = getattr(stream, "cuda_stream", stream)
+        self._call("rip_set_stream", C.c_void_p(int(handle) if handle else 0))
+
+    # ---- frame API -------------------------------------------------------------------------------
+    def query_output(self, rows, cols, channels, encoding):
+        r, c, cn = C.c_int(), C.c_int(), C.c_int()
+        enc = C.create_string_buffer(32)
+        self._call("rip_query_output", int(rows), int(cols), int(channels), encoding.encode(), C.byref(r), C.byref(c),
+                   C.byref(cn), enc)
+        return r.value, c.value, cn.value, enc.value.decode()
+
+    def process(self, image, encoding):
+        """cv::Mat process(const cv::Mat&, std::string&): returns a new array; input untouched."""
+        img = np.asarray(image)
+        if img.dtype != np.uint8 or img.ndim not in (2, 3):
+            raise ValueError("image must be uint8, HxW or HxWxC")
+        if img.strides[-1] != 1 or (img.ndim == 3 and img.strides[1] != img.shape[2]):
+            img = np.ascontiguousarray(img)
+        rows, cols = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        orows, ocols, ocn, _ = self.query_output(rows, cols, cn, encoding)
+        out = np.empty(orows * ocols * ocn, np.uint8)
+        r, c, k = C.c_int(), C.c_int(), C.c_int()
+        enc = C.create_string_buffer(32)
+        self._call("rip_apply", img.ctypes.data_as(C.c_void_p), rows, cols, cn, C.c_size_t(img.strides[0]),
+                   encoding.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(r), C.byref(c),
+                   C.byref(k), enc)
+        self.last_encoding = enc.value.decode()
+        return out.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
+
+    def apply(self, image, encoding):
+        """bool apply(cv::Mat&, std::string&): returns the processed image; when it has the input's
+        shape the input array is overwritten too (the reference re-seats the caller's Mat)."""
+        out = self.process(image, encoding)
+        if isinstance(image, np.ndarray) and image.shape == out.shape and image.flags.writeable:
+            image[...] = out
+        return out
+
+    def apply_device(self, frames, encoding, out=None, tap_debayered=None, tap_color=None):
+        """Device-resident batch (rip_apply_device).  ``frames``: uint8 CUDA tensor [n, rows, cols]
+        or [n, rows, cols, c] (torch) already in HBM; returns the output tensor [n, R, C(, 3)].
+        Asynchronous on the handle's stream."""
+        import torch
+        if frames.dtype != torch.uint8 or not frames.is_cuda:
+            raise ValueError("frames must be a uint8 CUDA tensor")
+        if frames.dim() == 3:
+            n, rows, cols = frames.shape
+            cn = 1
+        elif frames.dim() == 4:
+            n, rows, cols, cn = frames.shape
+        else:
+            raise ValueError("frames must be [n, rows, cols] or [n, rows, cols, c]")
+        if frames.stride(-1) != 1 or (frames.dim() == 4 and frames.stride(2) != cn):
+            raise ValueError("pixels must be contiguous")
+        in_step = frames.stride(1)
+        in_frame = frames.stride(0) if n > 1 else in_step * rows
+        orows, ocols, ocn, enc = self.query_output(rows, cols, cn, encoding)
+        shape = (n, orows, ocols) if ocn == 1 else (n, orows, ocols, ocn)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.uint8, device=frames.device)
+        elif tuple(out.shape) != shape or not out.is_contiguous():
+            raise ValueError("out must be a contiguous tensor of shape %s" % (shape,))
+        for t in (tap_debayered, tap_color):
+            if t is not None and (not t.is_contiguous() or t.dtype != torch.uint8):
+                raise ValueError("tap tensors must be contiguous uint8")
+        self._call("rip_apply_device", C.c_void_p(frames.data_ptr()), C.c_size_t(in_step), C.c_size_t(in_frame), int(n),
+                   int(rows), int(cols), int(cn), encoding.encode(), C.c_void_p(out.data_ptr()), C.c_size_t(0),
+                   C.c_size_t(0), C.c_void_p(tap_debayered.data_ptr() if tap_debayered is not None else 0),
+                   C.c_void_p(tap_color.data_ptr() if tap_color is not None else 0))
+        self.last_encoding = enc
+        return out
+
+    def set_taps(self, mask):
+        self._call("rip_set_taps", int(mask))
+
+    def _get_image(self, which):
+        r, c, k = C.c_int(), C.c_int(), C.c_int()
+        self._call("rip_get_image", which, None, C.c_size_t(0), C.byref(r), C.byref(c), C.byref(k))
+        if r.value == 0 or c.value == 0:
+            return np.empty((0, 0), np.uint8)
+        out = np.empty(r.value * c.value * k.value, np.uint8)
+        self._call("rip_get_image", which, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(r), C.byref(c),
+                   C.byref(k))
+        return out.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
+
+    def get_dist_debayered_image(self):
+        return self._get_image(IMAGE_DEBAYERED)
+
+    def get_dist_color_image(self):
+        return self._get_image(IMAGE_COLOR)
+
+    def get_rect_mask(self):
+        return self._get_image(IMAGE_RECT_MASK)
+
+    def get_processed_image(self):
+        return self._get_image(IMAGE_PROCESSED)
+
+    # ---- loaders ---------------------------------------------------------------------------------
+    def load_params(self, path):
+        self._call("rip_load_params", path.encode())
+
+    def load_camera_calibration(self, path):
+        self._call("rip_load_camera_calibration", path.encode())
+
+    def load_color_calibration(self, path):
+        self._call("rip_load_color_calibration", path.encode())
+
+    def init_undistortion(self):
+        self._call("rip_init_undistortion")
+
+    def load_ccc_model(self, path):
+        self._call("rip_load_ccc_model", path.encode())
+
+    def set_ccc_model(self, filt, bias):
+        filt = np.ascontiguousarray(filt, np.float32)
+        bias = np.ascontiguousarray(bias, np.float32)
+        if filt.shape != bias.shape or filt.ndim != 2:
+            raise ValueError("filter and bias must be 2-D arrays of the same shape")
+        self._call("rip_set_ccc_model", int(filt.shape[1]), int(filt.shape[0]), filt.ctypes.data_as(C.c_void_p),
+                   bias.ctypes.data_as(C.c_void_p))
+
+    def set_ccc_kalman_model(self, h, r):
+        self._call("rip_set_ccc_kalman_model", C.c_double(h), C.c_double(r))
+
+    # ---- other interfaces ------------------------------------------------------------------------
+    def reset_white_balance_temporal_consistency(self):
+        self._call("rip_reset_white_balance_temporal_consistency")
+
+    def set_gpu(self, use_gpu):
+        self._call("rip_set_gpu", int(bool(use_gpu)))
+
+    def set_debug(self, debug):
+        self._call("rip_set_debug", int(bool(debug)))
+
+    # ---- setters (names as in raw_image_pipeline_python.cpp:25-58) --------------------------------
+    def set_debayer(self, enabled):
+        self._call("rip_set_debayer", int(bool(enabled)))
+
+    def set_debayer_encoding(self, encoding):
+        self._call("rip_set_debayer_encoding", encoding.encode())
+
+    def set_flip(self, enabled):
+        self._call("rip_set_flip", int(bool(enabled)))
+
+    def set_flip_angle(self, angle):
+        self._call("rip_set_flip_angle", int(angle))
+
+    def set_white_balance(self, enabled):
+        self._call("rip_set_white_balance", int(bool(enabled)))
+
+    def set_white_balance_method(self, method):
+        self._call("rip_set_white_balance_method", method.encode())
+
+    def set_white_balance_percentile(self, percentile):
+        self._call("rip_set_white_balance_percentile", C.c_double(percentile))
+
+    def set_white_balance_saturation_threshold(self, bright_thr, dark_thr):
+        self._call("rip_set_white_balance_saturation_threshold", C.c_double(bright_thr), C.c_double(dark_thr))
+
+    def set_white_balance_temporal_consistency(self, enabled):
+        self._call("rip_set_white_balance_temporal_consistency", int(bool(enabled)))
+
+    def set_gamma_correction(self, enabled):
+        self._call("rip_set_gamma_correction", int(bool(enabled)))
+
+    def set_gamma_correction_method(self, method):
+        self._call("rip_set_gamma_correction_method", method.encode())
+
+    def set_gamma_correction_k(self, k):
+        self._call("rip_set_gamma_correction_k", C.c_double(k))
+
+    def set_vignetting_correction(self, enabled):
+        self._call("rip_set_vignetting_correction", int(bool(enabled)))
+
+    def set_vignetting_correction_parameters(self, scale, a2, a4):
+        self._call("rip_set_vignetting_correction_parameters", C.c_double(scale), C.c_double(a2), C.c_double(a4))
+
+    def set_color_enhancer(self, enabled):
+        self._call("rip_set_color_enhancer", int(bool(enabled)))
+
+    def set_color_enhancer_hue_gain(self, gain):
+        self._call("rip_set_color_enhancer_hue_gain", C.c_double(gain))
+
+    def set_color_enhancer_saturation_gain(self, gain):
+        self._call("rip_set_color_enhancer_saturation_gain", C.c_double(gain))
+
+    def set_color_enhancer_value_gain(self, gain):
+        self._call("rip_set_color_enhancer_value_gain", C.c_double(gain))
+
+    def set_color_calibration(self, enabled):
+        self._call("rip_set_color_calibration", int(bool(enabled)))
+
+    def set_color_calibration_matrix(self, matrix):
+        arr, n = _as_doubles(list(np.asarray(matrix, dtype=np.float64).reshape(-1)))
+        self._call("rip_set_color_calibration_matrix", arr, n)
+
+    def set_color_calibration_bias(self, bias):
+        arr, n = _as_doubles(list(np.asarray(bias, dtype=np.float64).reshape(-1)))
+        self._call("rip_set_color_calibration_bias", arr, n)
+
+    def set_undistortion(self, enabled):
+        self._call("rip_set_undistortion", int(bool(enabled)))
+
+    def set_undistortion_image_size(self, width, height):
+        self._call("rip_set_undistortion_image_size", int(width), int(height))
+
+    def set_undistortion_new_image_size(self, width, height):
+        self._call("rip_set_undistortion_new_image_size", int(width), int(height))
+
+    def set_undistortion_balance(self, balance):
+        self._call("rip_set_undistortion_balance", C.c_double(balance))
+
+    def set_undistortion_fov_scale(self, fov_scale):
+        self._call("rip_set_undistortion_fov_scale", C.c_double(fov_scale))
+
+    def _set_vec(self, name, values):
+        arr, n = _as_doubles(list(np.asarray(values, dtype=np.float64).reshape(-1)))
+        self._call(name, arr, n)
+
+    def set_undistortion_camera_matrix(self, m):
+        self._set_vec("rip_set_undistortion_camera_matrix", m)
+
+    def set_undistortion_distortion_coeffs(self, d):
+        self._set_vec("rip_set_undistortion_distortion_coefficients", d)
+
+    def set_undistortion_distortion_model(self, model):
+        self._call("rip_set_undistortion_distortion_model", model.encode())
+
+    def set_undistortion_rectification_matrix(self, m):
+        self._set_vec("rip_set_undistortion_rectification_matrix", m)
+
+    def set_undistortion_projection_matrix(self, m):
+        self._set_vec("rip_set_undistortion_projection_matrix", m)
+
+    # ---- getters -----------------------------------------------------------------------------------
+    def _flag(self, name):
+        return bool(getattr(self._lib, name)(self._h))
+
+    def is_debayer_enabled(self):
+        return self._flag("rip_is_debayer_enabled")
+
+    def is_flip_enabled(self):
+        return self._flag("rip_is_flip_enabled")
+
+    def is_white_balance_enabled(self):
+        return self._flag("rip_is_white_balance_enabled")
+
+    def is_color_calibration_enabled(self):
+        return self._flag("rip_is_color_calibration_enabled")
+
+    def is_gamma_correction_enabled(self):
+        return self._flag("rip_is_gamma_correction_enabled")
+
+    def is_vignetting_correction_enabled(self):
+        return self._flag("rip_is_vignetting_correction_enabled")
+
+    def is_color_enhancer_enabled(self):
+        return self._flag("rip_is_color_enhancer_enabled")
+
+    def is_undistortion_enabled(self):
+        return self._flag("rip_is_undistortion_enabled")
+
+    def get_dist_image_height(self):
+        return int(self._lib.rip_get_dist_image_height(self._h))
+
+    def get_dist_image_width(self):
+        return int(self._lib.rip_get_dist_image_width(self._h))
+
+    def get_rect_image_height(self):
+        return int(self._lib.rip_get_rect_image_height(self._h))
+
+    def get_rect_image_width(self):
+        return int(self._lib.rip_get_rect_image_width(self._h))
+
+    def _string(self, name):
+        buf = C.create_string_buffer(64)
+        self._call(name, buf, C.c_size_t(64))
+        return buf.value.decode()
+
+    def get_dist_distortion_model(self):
+        return self._string("rip_get_dist_distortion_model")
+
+    def get_rect_distortion_model(self):
+        return self._string("rip_get_rect_distortion_model")
+
+    def _matrix(self, name, shape):
+        n = int(np.prod(shape))
+        buf = (C.c_double * n)()
+        self._call(name, buf)
+        return np.array(buf, dtype=np.float64).reshape(shape)
+
+    def get_color_calibration_matrix(self):
+        return self._matrix("rip_get_color_calibration_matrix", (3, 3))
+
+    def get_color_calibration_bias(self):
+        return self._matrix("rip_get_color_calibration_bias", (4, 1))
+
+    def get_dist_camera_matrix(self):
+        return self._matrix("rip_get_dist_camera_matrix", (3, 3))
+
+    def get_dist_distortion_coefficients(self):
+        return self._matrix("rip_get_dist_distortion_coefficients", (1, 4))
+
+    def get_dist_rectification_matrix(self):
+        return self._matrix("rip_get_dist_rectification_matrix", (3, 3))
+
+    def get_dist_projection_matrix(self):
+        return self._matrix("rip_get_dist_projection_matrix", (3, 4))
+
+    def get_rect_camera_matrix(self):
+        return self._matrix("rip_get_rect_camera_matrix", (3, 3))
+
+    def get_rect_distortion_coefficients(self):
+        return self._matrix("rip_get_rect_distortion_coefficients", (1, 4))
+
+    def get_rect_rectification_matrix(self):
+        return self._matrix("rip_get_rect_rectification_matrix", (3, 3))
+
+    def get_rect_projection_matrix(self):
+        return self._matrix("rip_get_rect_projection_matrix", (3, 4))
+
+    # ---- introspection ------------------------------------------------------------------------------
+    def get_undistortion_maps(self):
+        r, c = C.c_int(), C.c_int()
+        self._call("rip_get_undistortion_maps", None, None, C.c_size_t(0), C.byref(r), C.byref(c))
+        mx = np.empty((r.value, c.value), np.float32)
+        my = np.empty((r.value, c.value), np.float32)
+        self._call("rip_get_undistortion_maps", mx.ctypes.data_as(C.c_void_p), my.ctypes.data_as(C.c_void_p),
+                   C.c_size_t(mx.size), C.byref(r), C.byref(c))
+        return mx, my
+
+    def get_white_balance_info(self, n_frames=1):
+        buf = np.empty((n_frames, 8), np.float32)
+        self._call("rip_get_white_balance_info", buf.ctypes.data_as(C.c_void_p), int(n_frames))
+        return buf
+
+    def get_table(self, which):
+        buf = np.empty(4096, np.int32)
+        n = self._lib.rip_get_table(self._h, int(which), buf.ctypes.data_as(C.c_void_p), 4096)
+        if n < 0:
+            raise ValueError("unknown table id")
+        return buf[:n].copy()

@@ -1,0 +1,245 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+inputs.  Bars (BASELINE.json north_star / BASELINE.md section 4): flip and LUT gamma bit-exact;
+debayer / remap within +-1 LSB; the other stages +-1 LSB as declared by the build.  The oracle is
+an integer/IEEE restatement, so every test below in fact demands tol = 0."""
+import numpy as np
+import pytest
+
+from helpers import assert_images_equal, cfg, configure, oracle_run
+from raw_image_pipeline_amd import RipAssertError, synth
+
+pytestmark = pytest.mark.gpu
+
+PATTERNS = ["bayer_rggb8", "bayer_grbg8", "bayer_gbrg8", "bayer_bggr8"]
+TOL_EXACT = 0        # flip, gamma LUT: bit-exact (north_star)
+TOL_INTERP = 0       # debayer, remap: north_star allows 1 LSB; the integer restatement is exact
+TOL_DECLARED = 0     # wb gains, colour matrix, hsv, vignetting: build declares 1 LSB; measured 0
+
+
+def run_both(pipe, O, c, frame, encoding, tol, ccc=None, what=""):
+    configure(pipe, c)
+    got = pipe.process(frame, encoding)
+    ref, enc = oracle_run(O, c, frame, encoding, ccc=ccc)
+    assert pipe.last_encoding == enc
+    assert_images_equal(got, ref, what, tol)
+    return got
+
+
+@pytest.mark.parametrize("pattern", PATTERNS)
+@pytest.mark.parametrize("size", [(64, 48), (132, 36), (37, 29), (6, 4), (3, 3), (5, 8)])
+@pytest.mark.parametrize("kind", ["uniform", "scene"])
+def test_debayer(gpu_pipe, oracle, pattern, size, kind):
+    w, h = size
+    frame = synth.gen_frame(w, h, pattern, seed=w * 1000 + h, kind=kind)
+    run_both(gpu_pipe, oracle, cfg(), frame, pattern, TOL_INTERP, what="debayer %s %s" % (pattern, size))
+
+
+@pytest.mark.parametrize("angle", [0, 90, 180, 270, 45])
+@pytest.mark.parametrize("size", [(64, 48), (37, 29)])
+def test_flip_after_debayer(gpu_pipe, oracle, angle, size):
+    w, h = size
+    frame = synth.gen_frame(w, h, "bayer_gbrg8", seed=angle, kind="uniform")
+    got = run_both(gpu_pipe, oracle, cfg(flip=True, flip_angle=angle), frame, "bayer_gbrg8", TOL_EXACT, what="flip %d" % angle)
+    assert got.shape[:2] == ((w, h) if angle in (90, 270) else (h, w))
+
+
+@pytest.mark.parametrize("encoding,cn", [("bgr8", 3), ("rgb8", 3), ("mono8", 1)])
+@pytest.mark.parametrize("angle", [90, 180, 270])
+def test_flip_colour_and_mono_inputs(gpu_pipe, oracle, encoding, cn, angle):
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (30, 44, cn) if cn == 3 else (30, 44), dtype=np.uint8)
+    run_both(gpu_pipe, oracle, cfg(flip=True, flip_angle=angle, gamma=True, gamma_k=0.9), img, encoding, TOL_EXACT,
+             what="%s flip %d" % (encoding, angle))
+    if encoding == "rgb8":
+        assert gpu_pipe.last_encoding == "rgb8"  # debayer.cpp:72-73: the CPU path keeps the string
+
+
+def test_flip_twice_is_identity(gpu_pipe):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    configure(gpu_pipe, cfg(flip=True, flip_angle=180))
+    once = gpu_pipe.process(img, "bgr8")
+    assert np.array_equal(gpu_pipe.process(once, "bgr8"), img)
+    configure(gpu_pipe, cfg(flip=True, flip_angle=90))
+    r90 = gpu_pipe.process(img, "bgr8")
+    configure(gpu_pipe, cfg(flip=True, flip_angle=270))
+    assert np.array_equal(gpu_pipe.process(r90, "bgr8"), img)
+
+
+@pytest.mark.parametrize("k", [0.8, 0.9, 1.0, 2.2])
+def test_gamma(gpu_pipe, oracle, k):
+    frame = synth.gen_frame(64, 48, "bayer_rggb8", seed=11, kind="uniform")
+    run_both(gpu_pipe, oracle, cfg(gamma=True, gamma_k=k), frame, "bayer_rggb8", TOL_EXACT, what="gamma %g" % k)
+
+
+def test_gamma_default_method_equals_custom(gpu_pipe, oracle):
+    frame = synth.gen_frame(640, 480, "bayer_rggb8", seed=0, kind="scene")  # BASELINE config 1
+    a = run_both(gpu_pipe, oracle, cfg(gamma=True, gamma_k=0.8, gamma_method="default"), frame, "bayer_rggb8", TOL_EXACT)
+    b = run_both(gpu_pipe, oracle, cfg(gamma=True, gamma_k=0.8, gamma_method="custom"), frame, "bayer_rggb8", TOL_EXACT)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("method", ["grey_world", "gray_world", "pca"])
+@pytest.mark.parametrize("kind,size", [("scene", (128, 96)), ("uniform", (64, 48)), ("scene", (51, 33))])
+def test_white_balance_statistics_methods(gpu_pipe, oracle, method, kind, size):
+    frame = synth.gen_frame(size[0], size[1], "bayer_rggb8", seed=5, kind=kind)
+    run_both(gpu_pipe, oracle, cfg(wb=True, wb_method=method, wb_bright=0.8), frame, "bayer_rggb8", TOL_DECLARED,
+             what="wb %s %s" % (method, kind))
+
+
+def test_grey_world_gains_match_oracle(gpu_pipe, oracle):
+    frame = synth.gen_frame(128, 96, "bayer_grbg8", seed=9, kind="scene")
+    configure(gpu_pipe, cfg(wb=True, wb_method="grey_world", wb_bright=0.9))
+    gpu_pipe.process(frame, "bayer_grbg8")
+    info = gpu_pipe.get_white_balance_info(1)[0]
+    _, sums, ig = oracle.wb_grayworld(oracle.debayer(frame, "bayer_grbg8"), 0.9, return_stats=True)
+    assert [int(v) for v in info[3:6]] == ig
+
+
+def test_color_calibration(gpu_pipe, oracle):
+    frame = synth.gen_frame(64, 48, "bayer_rggb8", seed=2, kind="uniform")
+    run_both(gpu_pipe, oracle, cfg(cc=True), frame, "bayer_rggb8", TOL_DECLARED, what="cc example matrix")
+    run_both(gpu_pipe, oracle, cfg(cc=True, cc_matrix=[0.5, 0.25, 0.25, -0.5, 1.5, 0.1, 0.3, 0.3, 0.41], cc_bias=(3.5, -7.25, 10.0)),
+             frame, "bayer_rggb8", TOL_DECLARED, what="cc with bias")
+    got = run_both(gpu_pipe, oracle, cfg(cc=True, cc_matrix=[1, 0, 0, 0, 1, 0, 0, 0, 1]), frame, "bayer_rggb8", TOL_EXACT)
+    assert np.array_equal(got, oracle.debayer(frame, "bayer_rggb8"))  # identity matrix is a no-op
+
+
+@pytest.mark.parametrize("size", [(64, 48), (48, 64), (40, 40), (37, 29)])
+@pytest.mark.parametrize("gamma", [False, True])
+def test_vignetting(gpu_pipe, oracle, size, gamma):
+    frame = synth.gen_frame(size[0], size[1], "bayer_rggb8", seed=4, kind="uniform")
+    run_both(gpu_pipe, oracle, cfg(vig=True, gamma=gamma, flip=True, flip_angle=180), frame, "bayer_rggb8", TOL_DECLARED,
+             what="vignetting %s gamma=%s" % (size, gamma))
+
+
+def test_vignetting_dark_and_saturated_pixels(gpu_pipe, oracle):
+    # exercises both branches of abToXZ (dark pixels take the linear segment) and the clamps
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    img[:16] //= 16
+    img[16:24] = 0
+    img[24:32] = 255
+    img[32:40, :, 0] = 255
+    img[32:40, :, 1:] //= 32
+    run_both(gpu_pipe, oracle, cfg(vig=True, vig_params=(2.5, 2e-3, 5e-6)), img, "bgr8", TOL_DECLARED, what="vignetting extremes")
+
+
+@pytest.mark.parametrize("gains", [(1.0, 1.2, 1.0), (1.0, 1.5, 1.0), (1.3, 0.7, 1.1), (1.0, 1.0, 1.0), (2.0, 3.0, 0.5)])
+def test_color_enhancer(gpu_pipe, oracle, gains):
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    img[:4] = img[:4, :, :1]  # grey rows: s == 0 branch
+    run_both(gpu_pipe, oracle, cfg(ce=True, ce_hue=gains[0], ce_sat=gains[1], ce_val=gains[2]), img, "bgr8", TOL_DECLARED,
+             what="hsv gains %s" % (gains,))
+
+
+@pytest.mark.parametrize("size", [(64, 48), (96, 80), (50, 38)])
+@pytest.mark.parametrize("balance,fov", [(0.0, 1.0), (0.5, 1.2), (1.0, 0.8)])
+def test_undistortion(gpu_pipe, oracle, size, balance, fov):
+    w, h = size
+    frame = synth.gen_frame(w, h, "bayer_rggb8", seed=6, kind="uniform")
+    c = cfg(undistort=True, cam=synth.camera_model(w, h), balance=balance, fov_scale=fov)
+    run_both(gpu_pipe, oracle, c, frame, "bayer_rggb8", TOL_INTERP, what="remap %s b=%g f=%g" % (size, balance, fov))
+
+
+def test_undistortion_mono_and_map_size_differs_from_image(gpu_pipe, oracle):
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (40, 56), dtype=np.uint8)
+    c = cfg(undistort=True, cam=synth.camera_model(64, 48))  # maps are 48x64, image is 40x56
+    got = run_both(gpu_pipe, oracle, c, img, "mono8", TOL_INTERP, what="remap mono")
+    assert got.shape == (48, 64)
+
+
+def full_chain_cfg(w, h, **kw):
+    base = dict(flip=True, flip_angle=180, wb=True, wb_method="grey_world", cc=True, gamma=True, gamma_k=0.8, vig=True,
+                undistort=True, cam=synth.camera_model(w, h))
+    base.update(kw)
+    return cfg(**base)
+
+
+@pytest.mark.parametrize("pattern", PATTERNS)
+def test_full_chain_config2_small(gpu_pipe, oracle, pattern):
+    w, h = 320, 240
+    frame = synth.gen_frame(w, h, pattern, seed=21, kind="scene")
+    run_both(gpu_pipe, oracle, full_chain_cfg(w, h), frame, pattern, 0, what="full chain %s" % pattern)
+
+
+def test_full_chain_with_enhancer_and_taps(gpu_pipe, oracle):
+    w, h = 160, 120
+    frame = synth.gen_frame(w, h, "bayer_rggb8", seed=22, kind="scene")
+    c = full_chain_cfg(w, h, ce=True, ce_sat=1.2)
+    configure(gpu_pipe, c)
+    got = gpu_pipe.process(frame, "bayer_rggb8")
+    ref, enc, t_deb, t_col = oracle_run(oracle, c, frame, "bayer_rggb8", taps=True)
+    assert_images_equal(got, ref, "final")
+    assert_images_equal(gpu_pipe.get_dist_debayered_image(), t_deb.reshape(h, w, 3), "debayered tap")
+    assert_images_equal(gpu_pipe.get_dist_color_image(), t_col.reshape(h, w, 3), "colour tap")
+    assert_images_equal(gpu_pipe.get_processed_image(), ref, "processed tap")
+    assert gpu_pipe.get_rect_mask().size == 0
+
+
+def test_full_chain_full_size_2448x2048(gpu_pipe, oracle):
+    """BASELINE configs[1] at its real size, against the oracle (a few seconds of CPU)."""
+    w, h = 2448, 2048
+    frame = synth.gen_frame(w, h, "bayer_rggb8", seed=1000, kind="scene")
+    run_both(gpu_pipe, oracle, full_chain_cfg(w, h), frame, "bayer_rggb8", 0, what="full chain 2448x2048")
+
+
+def test_device_batch_equals_per_frame_and_respects_pitch(gpu_pipe, oracle):
+    import torch
+    w, h, n = 128, 96, 5
+    c = full_chain_cfg(w, h)
+    configure(gpu_pipe, c)
+    frames = np.stack([synth.gen_frame(w, h, "bayer_rggb8", seed=1000 + i, kind="scene", tint=(0.7 + 0.02 * i, 1.0, 0.55))
+                       for i in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    out = gpu_pipe.apply_device(dev, "bayer_rggb8")
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i in range(n):
+        ref, _ = oracle_run(oracle, c, frames[i], "bayer_rggb8")
+        assert_images_equal(out[i], ref, "batch frame %d" % i)
+    # padded rows (pitch > width): view into a wider buffer
+    wide = torch.zeros((n, h, w + 32), dtype=torch.uint8, device="cuda")
+    wide[:, :, :w] = dev
+    out2 = gpu_pipe.apply_device(wide[:, :, :w], "bayer_rggb8")
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), out)
+
+
+def test_ccc_white_balance_sequence_config3(gpu_pipe, oracle):
+    """BASELINE configs[2] scaled down: gbrg8, ccc with temporal consistency, HSV enhancer."""
+    w, h, n = 384, 240, 6
+    filt, bias = synth.ccc_model()
+    gpu_pipe.set_ccc_model(filt, bias)
+    for kal in [(0.0, 1.0), (1.0, 10.0)]:
+        occ = oracle.CCC(filt, bias)
+        occ.set_kalman_model(*kal)
+        gpu_pipe.set_ccc_kalman_model(*kal)
+        gpu_pipe.reset_white_balance_temporal_consistency()
+        c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=True, ce=True, ce_sat=1.2)
+        configure(gpu_pipe, c)
+        gpu_pipe.reset_white_balance_temporal_consistency()
+        for i in range(n):
+            tint = (0.70 + 0.10 * i / (n - 1), 1.0, 0.55)
+            frame = synth.gen_frame(w, h, "bayer_gbrg8", seed=2000 + i, kind="scene", tint=tint)
+            got = gpu_pipe.process(frame, "bayer_gbrg8")
+            ref, _ = oracle_run(oracle, c, frame, "bayer_gbrg8", ccc=occ)
+            assert_images_equal(got, ref, "ccc frame %d kalman %s" % (i, kal), TOL_DECLARED)
+
+
+def test_error_behaviour(gpu_pipe):
+    frame = synth.gen_frame(64, 48)
+    configure(gpu_pipe, cfg())
+    with pytest.raises(ValueError, match="valid pattern but is not supported"):
+        gpu_pipe.process(frame, "bayer_rggb16")  # debayer.cpp:76-78
+    configure(gpu_pipe, cfg(wb=True, wb_method="magic"))
+    with pytest.raises(ValueError, match="not supported"):
+        gpu_pipe.process(frame, "bayer_rggb8")  # white_balance.hpp:82-84
+    configure(gpu_pipe, cfg(vig=True))
+    with pytest.raises(RipAssertError):
+        gpu_pipe.process(frame, "mono8")  # cvtColor(BGR2Lab) on one channel
+    configure(gpu_pipe, cfg(wb=True, wb_method="grey_world", cc=True, ce=True))
+    out = gpu_pipe.process(frame, "mono8")  # 3-channel-only stages are skipped silently
+    assert np.array_equal(out, frame)
