@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the RAW image chain on MI355X, with the roofline of its dominant kernel
+and the CPU baseline beside it.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+torch.distributed.run with one rank per GPU.  A step is one pass of the hot path over one batch of
+synthetic frames that are already resident in HBM.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 2448x2048
+bayer_rggb8, full chain = debayer + flip(180) + grey-world WB + colour calibration + gamma(k=0.8)
++ vignetting + fisheye undistortion, `--batch` frames per step (default 64).  Frames are
+independent units, so ranks shard by camera stream with no data-path collective (weak scaling:
+every rank runs its own batch); RCCL is used only for the barrier and the max-over-ranks time.
+
+Other workloads (for development, not the driver's line): --workload chain (configs 2a: the fused
+per-pixel kernel alone), config3 (1920x1200 gbrg8, ccc + enhancer), config5 (3840x2160 debayer +
+remap).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+# algorithmic bytes per pixel of each kernel class: compulsory traffic of the
+# fused schedule
+BYTES_PER_PX = {
+    "stats": 1.0,   # Bayer read (grey-world / pca pre-pass)
+    "ccc": 0.0,     # reads 4 x 360 x 270 taps per frame: O(1) per frame
+    "chain": 4.0,   # 1 B Bayer read + 3 B BGR write
+    "remap": 14.0,  # 8 B float2 map + 3 B gather + 3 B write
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--workload", default="config2", choices=["config2", "chain", "config3", "config5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def make_frames(width, height, pattern, batch, rank, distinct=4):
+    """`batch` synthetic Bayer frames: `distinct` seeded scenes (seed = 1000*camera + frame) plus
+    even-offset rolls of them (keeps the Bayer phase, changes every pixel's neighbourhood)."""
+    from raw_image_pipeline_amd import synth
+    base = [synth.gen_frame(width, height, pattern, seed=1000 * rank + i, kind="scene") for i in range(min(distinct, batch))]
+    frames = []
+    for i in range(batch):
+        f = base[i % len(base)]
+        k = i // len(base)
+        frames.append(np.roll(f, (2 * k, 4 * k), axis=(0, 1)) if k else f)
+    return np.stack(frames)
+
+
+def configure(pipe, workload, width, height):
+    from raw_image_pipeline_amd import synth
+    pattern = "bayer_rggb8"
+    if workload == "config2":
+        synth.configure_full_chain(pipe, width, height, "grey_world")
+        stages = "debayer+flip180+grey_world+color_calib+gamma+vignetting+undistort"
+    elif workload == "chain":
+        synth.configure_full_chain(pipe, width, height, "grey_world")
+        pipe.set_white_balance(False)  # gains only matter through the statistics pre-pass
+        pipe.set_undistortion(False)
+        stages = "debayer+flip180+color_calib+gamma+vignetting (fused per-pixel kernel only)"
+    elif workload == "config3":
+        pattern = "bayer_gbrg8"
+        filt, bias = synth.ccc_model()
+        pipe.set_ccc_model(filt, bias)
+        pipe.set_flip(False)
+        pipe.set_white_balance(True)
+        pipe.set_white_balance_method("ccc")
+        pipe.set_white_balance_saturation_threshold(0.8, 0.2)
+        pipe.set_white_balance_temporal_consistency(True)
+        pipe.set_color_calibration(False)
+        pipe.set_gamma_correction(False)
+        pipe.set_vignetting_correction(False)
+        pipe.set_color_enhancer(True)
+        pipe.set_color_enhancer_saturation_gain(1.2)
+        pipe.set_undistortion(False)
+        stages = "debayer+ccc(temporal)+color_enhancer"
+    else:  # config5
+        pipe.set_flip(False)
+        pipe.set_white_balance(False)
+        pipe.set_color_calibration(False)
+        pipe.set_gamma_correction(False)
+        pipe.set_vignetting_correction(False)
+        pipe.set_color_enhancer(False)
+        pipe.set_undistortion(True)
+        synth.load_camera(pipe, synth.camera_model(width, height))
+        stages = "debayer+undistort"
+    return pattern, stages
+
+
+def cpu_baseline(width, height, pattern, seconds):
+    """The oracle (CPU restatement of the reference's OpenCV path, reference-faithful schedule)
+    timed on this box's host cores, one frame per thread -- the one-process-per-camera deployment
+    of the reference.  A bounded sample: whole rounds of `cores` frames until ~`seconds` elapse."""
+    import threading
+    import oracle as O
+    from raw_image_pipeline_amd import synth
+    O.build()
+    cores = os.cpu_count() or 1
+    cam = synth.camera_model(width, height)
+    newK = O.fisheye_new_camera_matrix(cam["K"], cam["D"], (width, height), cam["R"], 0.0, None, 1.0)
+    mx, my = O.fisheye_maps(cam["K"], cam["D"], cam["R"], newK, (width, height))
+    prm = O.Params()
+    prm.flip_enabled, prm.flip_angle = 1, 180
+    prm.wb_enabled, prm.wb_method, prm.wb_bright_thr, prm.wb_dark_thr = 1, 1, 0.8, 0.2
+    prm.cc_enabled, prm.cc_available = 1, 1
+    for i, v in enumerate(synth.COLOR_MATRIX):
+        prm.cc_matrix[i] = v
+    prm.gamma_enabled, prm.gamma_k = 1, 0.8
+    prm.vig_enabled, prm.vig_scale, prm.vig_a2, prm.vig_a4 = 1, 1.5, 1e-3, 1e-6
+    prm.und_enabled = 1
+    prm.map_x, prm.map_y = mx.ctypes.data, my.ctypes.data
+    prm.map_rows, prm.map_cols = height, width
+    prm.reference_schedule = 1
+    frame = synth.gen_frame(width, height, pattern, seed=0, kind="scene")
+
+    def work():
+        O.pipeline(prm, frame, pattern)
+
+    work()  # warm-up (page faults, table init)
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        th = [threading.Thread(target=work) for _ in range(cores)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        done += cores
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 64 * cores:
+            break
+    return {"value": round(done / el, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same %dx%d %s full chain, oracle in the reference-faithful schedule "
+                      "(per-stage passes, 4 frame copies, mask rebuilt per frame), %d threads x 1 frame, %.1f s"
+                      % (done, width, height, pattern, cores, el)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the pipeline has no CPU execution path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from raw_image_pipeline_amd import RawImagePipeline
+
+    dims = {"config2": (2448, 2048), "chain": (2448, 2048), "config3": (1920, 1200), "config5": (3840, 2160)}
+    width, height = dims[args.workload]
+    pipe = RawImagePipeline(False, "", "", "", device=local_rank)
+    pipe.set_stream(torch.cuda.current_stream())
+    pattern, stages = configure(pipe, args.workload, width, height)
+
+    frames = torch.from_numpy(make_frames(width, height, pattern, args.batch, rank)).cuda()
+    orows, ocols, ocn, _ = pipe.query_output(height, width, 1, pattern)
+    out = torch.empty((args.batch, orows, ocols, ocn), dtype=torch.uint8, device="cuda")
+
+    def step():
+        pipe.apply_device(frames, pattern, out=out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    pipe.profile_begin(4 * args.steps + 8)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = pipe.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_frames = args.batch * args.steps * world
+    fps = total_frames / elapsed
+
+    # roofline of the dominant kernel class, from the HIP events recorded around its launches
+    px = width * height
+    dom = max(prof, key=lambda k: prof[k][0])
+    dom_ms, dom_n = prof[dom]
+    per_launch_bytes = BYTES_PER_PX[dom] * px * args.batch
+    avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
+    achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as f:
+                traffic = json.load(f).get(args.workload, {}).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_s * 1e3, 4),
+                "launches": dom_n,
+                "kernel_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()}}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    result = {
+        "metric": "frames/sec at 2448x2048 bayer_rggb8 full chain; achieved HBM GB/s vs roofline",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%dx%d %s, %s" % (width, height, pattern, stages), "frames_per_step_per_gpu": args.batch,
+                   "sharding": "one camera stream per GPU, no data-path collective", "name": args.workload},
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline and world == 1 and args.workload == "config2":
+        result["cpu_baseline"] = cpu_baseline(width, height, pattern, args.cpu_seconds)
+    elif world == 1:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

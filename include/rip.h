@@ -198,6 +198,13 @@ rip_status rip_get_undistortion_maps(rip_pipeline* p, float* map_x, float* map_y
 /* Per-frame white-balance results of the most recent device batch (D2H, synchronises):
  * for frame f, out[f*8 ..] = {gain_b, gain_g, gain_r, q8_b, q8_g, q8_r, uv_x, uv_y}. */
 rip_status rip_get_white_balance_info(rip_pipeline* p, float* out, int n_frames);
+/* Per-kernel-class timing with HIP events recorded on the handle's stream around each launch
+ * (what bench.py's roofline leg reads).  rip_profile_begin arms up to max_records event pairs;
+ * rip_profile_end synchronises the stream and returns, per class, the summed elapsed
+ * milliseconds and the number of launches recorded. */
+enum { RIP_KERNEL_STATS = 0, RIP_KERNEL_CCC = 1, RIP_KERNEL_CHAIN = 2, RIP_KERNEL_REMAP = 3, RIP_KERNEL_COUNT = 4 };
+rip_status rip_profile_begin(rip_pipeline* p, int max_records);
+rip_status rip_profile_end(rip_pipeline* p, double ms_sum[4], int count[4]);
 /* Host-built tables the kernels use (same ids as oracle ripo_table, plus 8: gamma LUT). */
 int rip_get_table(rip_pipeline* p, int which, int32_t* out, int capacity);
 const char* rip_version(void);

@@ -126,6 +126,11 @@ struct rip_pipeline {
   // per-batch scratch
   DevBuf d_stats, d_wb, d_hist, d_work, d_rowbest, d_argmax, d_mid;
   int last_batch_frames = 0;
+  // optional per-kernel timing with HIP events on the handle's stream (bench.py roofline leg)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_events;  // pairs
+  std::vector<int> prof_ids;
+  size_t prof_used = 0;
   // host-apply staging and last-frame taps
   DevBuf d_in, d_out, d_tap_deb, d_tap_col;
   int last_rows[3] = {0, 0, 0}, last_cols[3] = {0, 0, 0}, last_cn[3] = {0, 0, 0};
@@ -135,6 +140,7 @@ struct rip_pipeline {
   ~rip_pipeline() {
     if (device < 0) return;
     (void)hipSetDevice(device);
+    for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
     for (DevBuf* b : {&d_tabs, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
                       &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col})
       b->release();
@@ -142,6 +148,22 @@ struct rip_pipeline {
 };
 
 namespace {
+
+// RAII marker: records an event pair around the launches of one kernel class when profiling is on
+struct ProfScope {
+  rip_pipeline* p;
+  size_t slot = (size_t)-1;
+  ProfScope(rip_pipeline* pp, int id) : p(pp) {
+    if (!p->prof_on || p->prof_used + 2 > p->prof_events.size()) return;
+    slot = p->prof_used;
+    p->prof_used += 2;
+    p->prof_ids.push_back(id);
+    (void)hipEventRecord(p->prof_events[slot], p->stream);
+  }
+  ~ProfScope() {
+    if (slot != (size_t)-1) (void)hipEventRecord(p->prof_events[slot + 1], p->stream);
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
 // undistortion bookkeeping: UndistortionModule::init() (undistortion.cpp:197-238) minus the map
@@ -396,7 +418,10 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     sp.mode = pl.wb_mode;
     sp.thresh255 = (unsigned)(uint16_t)std::lrintf((float)p->m.wb_bright_thr * 255);
     sp.stats = p->d_stats.as<rip::FrameStats>();
-    rip::launch_stats(sp, p->stream);
+    {
+      ProfScope ps(p, RIP_KERNEL_STATS);
+      rip::launch_stats(sp, p->stream);
+    }
     rip::launch_wb_finalize(pl.wb_mode, sp.stats, nullptr, nullptr, p->d_tabs.as<rip::DevTables>(), p->d_wb.as<rip::FrameWb>(), n,
                             p->stream);
   } else if (pl.wb_mode == rip::WB_FLOAT) {
@@ -441,7 +466,10 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     cp.row_best = p->d_rowbest.as<float>();
     cp.argmax = p->d_argmax.as<int>();
     cp.tabs = p->d_tabs.as<rip::DevTables>();
-    rip::launch_ccc_estimate(cp, p->stream);
+    {
+      ProfScope ps(p, RIP_KERNEL_CCC);
+      rip::launch_ccc_estimate(cp, p->stream);
+    }
     rip::launch_wb_finalize(rip::WB_FLOAT, nullptr, cp.argmax, p->d_ccc_state.as<rip::CccState>(), cp.tabs, p->d_wb.as<rip::FrameWb>(),
                             n, p->stream);
   }
@@ -498,7 +526,10 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   c.hsv_gain[1] = (float)p->m.ce_saturation_gain;
   c.hsv_gain[2] = (float)p->m.ce_value_gain;
   c.tabs = p->d_tabs.as<rip::DevTables>();
-  rip::launch_chain(c, p->stream);
+  {
+    ProfScope ps(p, RIP_KERNEL_CHAIN);
+    rip::launch_chain(c, p->stream);
+  }
   if (!pl.remap && d_tap_col) {
     // pre-undistortion copy == final image when no remap follows
     for (int f = 0; f < n; f++)
@@ -521,6 +552,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     r.drows = pl.out_rows;
     r.dcols = pl.out_cols;
     r.n_frames = n;
+    ProfScope ps(p, RIP_KERNEL_REMAP);
     rip::launch_remap(r, p->stream);
   }
   hipError_t le = hipGetLastError();
@@ -559,6 +591,7 @@ rip_status guarded(const rip_pipeline* p, F&& fn) {
 void need(const rip_pipeline* p) {
   if (!p) throw InvalidArgument("null pipeline handle");
 }
+
 void need_device(const rip_pipeline* p) {
   need(p);
   if (p->device == RIP_DEVICE_NONE)
@@ -985,6 +1018,43 @@ rip_status rip_get_white_balance_info(rip_pipeline* p, float* out, int n_frames)
       o[3] = (float)h[f].q8[0]; o[4] = (float)h[f].q8[1]; o[5] = (float)h[f].q8[2];
       o[6] = (float)h[f].uv[0]; o[7] = (float)h[f].uv[1];
     }
+  });
+}
+
+rip_status rip_profile_begin(rip_pipeline* p, int max_records) {
+  return guarded(p, [&] {
+    need_device(p);
+    HIP_CHECK(hipSetDevice(p->device));
+    if (max_records < 0) throw InvalidArgument("negative record count");
+    while (p->prof_events.size() < (size_t)max_records * 2) {
+      hipEvent_t e;
+      HIP_CHECK(hipEventCreate(&e));
+      p->prof_events.push_back(e);
+    }
+    p->prof_used = 0;
+    p->prof_ids.clear();
+    p->prof_on = max_records > 0;
+  });
+}
+
+rip_status rip_profile_end(rip_pipeline* p, double ms_sum[RIP_KERNEL_COUNT], int count[RIP_KERNEL_COUNT]) {
+  return guarded(p, [&] {
+    need_device(p);
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    for (int i = 0; i < RIP_KERNEL_COUNT; i++) {
+      if (ms_sum) ms_sum[i] = 0;
+      if (count) count[i] = 0;
+    }
+    for (size_t r = 0; r < p->prof_ids.size(); r++) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, p->prof_events[2 * r], p->prof_events[2 * r + 1]));
+      if (ms_sum) ms_sum[p->prof_ids[r]] += ms;
+      if (count) count[p->prof_ids[r]]++;
+    }
+    p->prof_on = false;
+    p->prof_used = 0;
+    p->prof_ids.clear();
   });
 }
 

@@ -41,6 +41,12 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    try:
+        # torch bundles its own libamdhip64 (same soname as ROCm's): import it first so that this
+        # library binds to the SAME HIP runtime -- device pointers and streams are shared with torch.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: build it with `python raw_image_pipeline_amd/build.py` "
                            "(hipcc, gfx950). The pipeline has no CPU fallback." % path)
@@ -450,6 +456,18 @@ class RawImagePipeline:
         buf = np.empty((n_frames, 8), np.float32)
         self._call("rip_get_white_balance_info", buf.ctypes.data_as(C.c_void_p), int(n_frames))
         return buf
+
+    KERNEL_CLASSES = ("stats", "ccc", "chain", "remap")
+
+    def profile_begin(self, max_records):
+        self._call("rip_profile_begin", int(max_records))
+
+    def profile_end(self):
+        """-> {class: (total_ms, launches)} from HIP events on the handle's stream."""
+        ms = (C.c_double * 4)()
+        cnt = (C.c_int * 4)()
+        self._call("rip_profile_end", ms, cnt)
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
 
     def get_table(self, which):
         buf = np.empty(4096, np.int32)

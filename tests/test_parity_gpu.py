@@ -213,13 +213,17 @@ def test_ccc_white_balance_sequence_config3(gpu_pipe, oracle):
     w, h, n = 384, 240, 6
     filt, bias = synth.ccc_model()
     gpu_pipe.set_ccc_model(filt, bias)
+    # One stream on both sides: first the pipeline's degenerate Kalman model (H = 0, what the
+    # one-argument constructor leaves behind), then -- after resetWhiteBalanceTemporalConsistency,
+    # which only re-arms first_frame_ and keeps the covariance -- loadModel's H = I, R = 10 I.
+    occ = oracle.CCC(filt, bias)
+    c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=True, ce=True, ce_sat=1.2)
+    configure(gpu_pipe, c)
+    seen = []
     for kal in [(0.0, 1.0), (1.0, 10.0)]:
-        occ = oracle.CCC(filt, bias)
         occ.set_kalman_model(*kal)
+        occ.reset()
         gpu_pipe.set_ccc_kalman_model(*kal)
-        gpu_pipe.reset_white_balance_temporal_consistency()
-        c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=True, ce=True, ce_sat=1.2)
-        configure(gpu_pipe, c)
         gpu_pipe.reset_white_balance_temporal_consistency()
         for i in range(n):
             tint = (0.70 + 0.10 * i / (n - 1), 1.0, 0.55)
@@ -227,6 +231,9 @@ def test_ccc_white_balance_sequence_config3(gpu_pipe, oracle):
             got = gpu_pipe.process(frame, "bayer_gbrg8")
             ref, _ = oracle_run(oracle, c, frame, "bayer_gbrg8", ccc=occ)
             assert_images_equal(got, ref, "ccc frame %d kalman %s" % (i, kal), TOL_DECLARED)
+            seen.append(tuple(int(v) for v in gpu_pipe.get_white_balance_info(1)[0][6:8]))
+    assert len(set(seen[:n])) == 1, "H = 0: the estimate must stay frozen at the first frame's argmax"
+    assert len(set(seen[n:])) > 1, "H = I: the estimate must follow the drifting tint"
 
 
 def test_error_behaviour(gpu_pipe):
