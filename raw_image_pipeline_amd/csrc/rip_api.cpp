@@ -125,6 +125,11 @@ struct rip_pipeline {
   int geom_rows = -1, geom_cols = -1;
   // per-batch scratch
   DevBuf d_stats, d_wb, d_hist, d_work, d_rowbest, d_argmax, d_mid;
+  // compiled remap plan (tiled LDS gather), rebuilt when the maps or the source geometry change
+  rip::RemapPlan plan;
+  DevBuf d_plan_words, d_plan_tiles;
+  bool plan_uploaded = false;
+  bool use_tiled_remap = true;
   int last_batch_frames = 0;
   // optional per-kernel timing with HIP events on the handle's stream (bench.py roofline leg)
   bool prof_on = false;
@@ -142,7 +147,8 @@ struct rip_pipeline {
     (void)hipSetDevice(device);
     for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
     for (DevBuf* b : {&d_tabs, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
-                      &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col})
+                      &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col, &d_plan_words,
+                      &d_plan_tiles})
       b->release();
   }
 };
@@ -192,6 +198,32 @@ void ensure_host_maps(rip_pipeline* p) {
   rip::fisheye_init_undistort_rectify_map(m.dist_K, m.dist_D, m.dist_R, m.rect_K, m.dist_w, m.dist_h, p->h_map.data());
   p->map_dirty = false;
   p->map_uploaded = false;
+  p->plan.valid = false;
+}
+
+void ensure_maps(rip_pipeline* p);
+
+static_assert(rip::kRemapOutside == rip::kPlanOutside && rip::kRemapBorder == rip::kPlanBorder, "plan sentinels");
+static_assert(sizeof(rip::RemapTile) == sizeof(rip::RemapTileDesc), "tile descriptor layout");
+
+void ensure_plan(rip_pipeline* p, int src_rows, int src_cols) {
+  ensure_maps(p);
+  const rip::Modules& m = p->m;
+  if (!p->plan.valid || p->plan.src_rows != src_rows || p->plan.src_cols != src_cols || p->plan.drows != m.dist_h ||
+      p->plan.dcols != m.dist_w) {
+    rip::compile_remap_plan(p->plan, p->h_map.data(), m.dist_h, m.dist_w, src_rows, src_cols);
+    p->plan_uploaded = false;
+  }
+  if (!p->plan_uploaded) {
+    p->d_plan_words.reserve(p->plan.words.size() * sizeof(uint32_t));
+    p->d_plan_tiles.reserve(p->plan.tiles.size() * sizeof(rip::RemapTile));
+    HIP_CHECK(hipMemcpyAsync(p->d_plan_words.ptr, p->plan.words.data(), p->plan.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                             p->stream));
+    HIP_CHECK(hipMemcpyAsync(p->d_plan_tiles.ptr, p->plan.tiles.data(), p->plan.tiles.size() * sizeof(rip::RemapTile),
+                             hipMemcpyHostToDevice, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->plan_uploaded = true;
+  }
 }
 
 void ensure_maps(rip_pipeline* p) {
@@ -338,6 +370,9 @@ Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const st
   const rip::Modules& m = p->m;
   Plan pl;
   if (rows < 1 || cols < 1) throw AssertError("empty image");
+  // the kernels address one frame with 32-bit byte offsets and 24-bit row multiplies
+  if (cols > (1 << 22) || rows > (1 << 22) || (unsigned long long)rows * cols * 3ull >= (1ull << 32))
+    throw InvalidArgument("image too large: a frame must stay below 4 GiB and 4 Mpx per side");
   pl.encoding_out = encoding;
   if (parse_bayer(encoding, pl.ry, pl.rx)) {
     if (channels != 1) throw AssertError("cv::demosaicing: Bayer input must have one channel");
@@ -395,8 +430,12 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
                int cols, uint8_t* d_out, size_t out_step, size_t out_frame_stride, uint8_t* d_tap_deb, uint8_t* d_tap_col) {
   HIP_CHECK(hipSetDevice(p->device));
   ensure_tables(p);
-  const size_t mid_pitch = (size_t)pl.mid_cols * pl.channels;
-  const size_t mid_frame = mid_pitch * pl.mid_rows;
+  const size_t tap_pitch = (size_t)pl.mid_cols * pl.channels;  // taps are tightly packed API outputs
+  const size_t tap_frame = tap_pitch * pl.mid_rows;
+  // the internal pre-undistortion image uses 16-byte aligned rows (the tiled remap stages it with
+  // aligned 16-byte loads); when that image is an API output the caller's tight pitch is used
+  size_t mid_pitch = d_tap_col ? tap_pitch : ((tap_pitch + 15) & ~(size_t)15);
+  size_t mid_frame = mid_pitch * pl.mid_rows;
   if (out_step == 0) out_step = (size_t)pl.out_cols * pl.channels;
   if (out_frame_stride == 0) out_frame_stride = out_step * pl.out_rows;
 
@@ -505,7 +544,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   c.dcols = pl.mid_cols;
   c.channels = pl.channels;
   c.tap = d_tap_deb;
-  c.tap_frame_stride = mid_frame;
+  c.tap_frame_stride = tap_frame;
   c.flip_angle = pl.flip_angle;
   c.n_frames = n;
   c.wb_mode = pl.wb_mode;
@@ -533,7 +572,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   if (!pl.remap && d_tap_col) {
     // pre-undistortion copy == final image when no remap follows
     for (int f = 0; f < n; f++)
-      HIP_CHECK(hipMemcpy2DAsync(d_tap_col + (size_t)f * mid_frame, mid_pitch, d_out + (size_t)f * out_frame_stride, out_step, mid_pitch,
+      HIP_CHECK(hipMemcpy2DAsync(d_tap_col + (size_t)f * tap_frame, tap_pitch, d_out + (size_t)f * out_frame_stride, out_step, tap_pitch,
                                  (size_t)pl.mid_rows, hipMemcpyDeviceToDevice, p->stream));
   }
   // ---- remap -----------------------------------------------------------------------------------
@@ -552,8 +591,23 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     r.drows = pl.out_rows;
     r.dcols = pl.out_cols;
     r.n_frames = n;
-    ProfScope ps(p, RIP_KERNEL_REMAP);
-    rip::launch_remap(r, p->stream);
+    bool done = false;
+    if (p->use_tiled_remap && pl.channels == 3) {
+      ensure_plan(p, pl.mid_rows, pl.mid_cols);
+      rip::RemapTiledParams tp = {};
+      tp.base = r;
+      tp.words = p->d_plan_words.as<uint32_t>();
+      tp.tiles = p->d_plan_tiles.as<rip::RemapTileDesc>();
+      tp.tiles_x = p->plan.tiles_x;
+      tp.tiles_y = p->plan.tiles_y;
+      tp.lds_bytes = (unsigned)p->plan.max_lds_bytes;
+      ProfScope ps(p, RIP_KERNEL_REMAP);
+      done = rip::launch_remap_tiled(tp, p->stream);
+    }
+    if (!done) {
+      ProfScope ps(p, RIP_KERNEL_REMAP);
+      rip::launch_remap(r, p->stream);
+    }
   }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) throw DeviceError(std::string("kernel launch failed: ") + hipGetErrorString(le));
@@ -648,6 +702,7 @@ rip_status rip_create(int device, int use_gpu, const char* params_path, const ch
       std::fprintf(stderr, "Warning: Color calibration file doesn't exist\n");
     }
     und_init(p);
+    if (const char* t = std::getenv("RIP_REMAP_TILED")) p->use_tiled_remap = std::atoi(t) != 0;
     const char* env = std::getenv("RIP_CCC_MODEL");
     if (env && *env) rip::ccc_load_model_file(p->ccc, env);
     *out = p;
@@ -802,8 +857,8 @@ rip_status rip_load_params(rip_pipeline* p, const char* path) {
   return guarded(p, [&] {
     need(p);
     if (!path) throw InvalidArgument("path is null");
-    std::printf("Loading raw_image_pipeline params from file %s\n", path);
-    if (!rip::load_params_file(p->m, path)) std::printf("Warning: parameters file doesn't exist\n");
+    std::fprintf(stderr, "Loading raw_image_pipeline params from file %s\n", path);
+    if (!rip::load_params_file(p->m, path)) std::fprintf(stderr, "Warning: parameters file doesn't exist\n");
     p->tabs_dirty = p->vig_dirty = p->ccc_cfg_dirty = true;
     und_init(p);  // setBalance / setFovScale re-run init()
   });
@@ -812,8 +867,8 @@ rip_status rip_load_camera_calibration(rip_pipeline* p, const char* path) {
   return guarded(p, [&] {
     need(p);
     if (!path) throw InvalidArgument("path is null");
-    std::printf("Loading camera calibration from file %s\n", path);
-    if (!rip::load_camera_calibration_file(p->m, path)) std::printf("Warning: Calibration file doesn't exist\n");
+    std::fprintf(stderr, "Loading camera calibration from file %s\n", path);
+    if (!rip::load_camera_calibration_file(p->m, path)) std::fprintf(stderr, "Warning: Calibration file doesn't exist\n");
     und_init(p);
   });
 }
@@ -821,8 +876,8 @@ rip_status rip_load_color_calibration(rip_pipeline* p, const char* path) {
   return guarded(p, [&] {
     need(p);
     if (!path) throw InvalidArgument("path is null");
-    std::printf("Loading color calibration from file %s\n", path);
-    if (!rip::load_color_calibration_file(p->m, path)) std::printf("Warning: Color calibration file doesn't exist\n");
+    std::fprintf(stderr, "Loading color calibration from file %s\n", path);
+    if (!rip::load_color_calibration_file(p->m, path)) std::fprintf(stderr, "Warning: Color calibration file doesn't exist\n");
   });
 }
 rip_status rip_init_undistortion(rip_pipeline* p) {

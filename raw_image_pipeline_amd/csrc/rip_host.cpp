@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -638,6 +639,107 @@ void fisheye_init_undistort_rectify_map(const double K[9], const double D[4], co
     if (r0 < r1) pool.emplace_back(rows_fn, r0, r1);
   }
   for (auto& th : pool) th.join();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Compiled remap plan
+// ---------------------------------------------------------------------------------------------
+namespace {
+inline int quantise_map(float v) {
+  // cvRound(v * INTER_TAB_SIZE) as cv::remap does (imgwarp.cpp); INT_MIN for NaN / inf / overflow
+  float s = v * 32.f;
+  if (!(s > -2147483648.f && s < 2147483648.f)) return INT32_MIN;
+  return (int)std::lrintf(s);
+}
+inline int sat_s16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+}  // namespace
+
+size_t remap_tile_lds_bytes(int w, int h) {
+  if (w <= 0 || h <= 0) return 0;
+  size_t pitch = (((size_t)w * 3 + 15 + 12) + 15) & ~(size_t)15;  // chunk-aligned start + 12 B read slack
+  return pitch * (size_t)h;
+}
+
+void compile_remap_plan(RemapPlan& plan, const float* map_xy, int drows, int dcols, int src_rows, int src_cols) {
+  plan = RemapPlan();
+  plan.drows = drows;
+  plan.dcols = dcols;
+  plan.src_rows = src_rows;
+  plan.src_cols = src_cols;
+  plan.tiles_x = (dcols + kRemapTileW - 1) / kRemapTileW;
+  plan.tiles_y = (drows + kRemapTileH - 1) / kRemapTileH;
+  const size_t ntiles = (size_t)plan.tiles_x * plan.tiles_y;
+  const int tile_px = kRemapTileW * kRemapTileH;
+  plan.words.assign(ntiles * tile_px, kRemapOutside);
+  plan.tiles.assign(ntiles, RemapTile{0, 0, 0, 0});
+  auto do_tiles = [&](size_t t0, size_t t1) {
+    std::vector<int> ix(tile_px), iy(tile_px);
+    for (size_t t = t0; t < t1; t++) {
+      const int ty = (int)(t / plan.tiles_x), tx = (int)(t % plan.tiles_x);
+      int minx = INT32_MAX, miny = INT32_MAX, maxx = INT32_MIN, maxy = INT32_MIN;
+      uint32_t* words = plan.words.data() + t * tile_px;
+      for (int r = 0; r < kRemapTileH; r++)
+        for (int c = 0; c < kRemapTileW; c++) {
+          const int y = ty * kRemapTileH + r, x = tx * kRemapTileW + c, k = r * kRemapTileW + c;
+          if (y >= drows || x >= dcols) {
+            words[k] = kRemapOutside;  // never stored
+            ix[k] = INT32_MIN;
+            continue;
+          }
+          const float* m = map_xy + ((size_t)y * dcols + x) * 2;
+          const int sxq = quantise_map(m[0]), syq = quantise_map(m[1]);
+          const int sx = sat_s16(sxq >> 5), sy = sat_s16(syq >> 5);
+          if (sx >= src_cols || sx + 1 < 0 || sy >= src_rows || sy + 1 < 0) {
+            words[k] = kRemapOutside;
+            ix[k] = INT32_MIN;
+          } else if (sx >= 0 && sx < src_cols - 1 && sy >= 0 && sy < src_rows - 1) {
+            words[k] = ((uint32_t)(sxq & 31) << 22) | ((uint32_t)(syq & 31) << 27);  // rel coords filled below
+            ix[k] = sx;
+            iy[k] = sy;
+            minx = std::min(minx, sx);
+            maxx = std::max(maxx, sx + 1);
+            miny = std::min(miny, sy);
+            maxy = std::max(maxy, sy + 1);
+          } else {
+            words[k] = kRemapBorder;
+            ix[k] = INT32_MIN;
+          }
+        }
+      RemapTile& tile = plan.tiles[t];
+      if (minx == INT32_MAX) continue;
+      tile.x0 = minx;
+      tile.y0 = miny;
+      tile.w = maxx - minx + 1;
+      tile.h = maxy - miny + 1;
+      if (tile.w > 2040 || tile.h > 2040) {
+        // footprint too large for the packed form: everything in this tile takes the per-tap path
+        for (int k = 0; k < tile_px; k++)
+          if (ix[k] != INT32_MIN) words[k] = kRemapBorder;
+        tile = RemapTile{0, 0, 0, 0};
+        continue;
+      }
+      for (int k = 0; k < tile_px; k++)
+        if (ix[k] != INT32_MIN) words[k] |= (uint32_t)(ix[k] - minx) | ((uint32_t)(iy[k] - miny) << 11);
+    }
+  };
+  int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (ntiles < 64 || nthreads == 1) {
+    do_tiles(0, ntiles);
+  } else {
+    std::vector<std::thread> pool;
+    size_t chunk = (ntiles + nthreads - 1) / nthreads;
+    for (int i = 0; i < nthreads; i++) {
+      size_t a = i * chunk, b = std::min(ntiles, a + chunk);
+      if (a < b) pool.emplace_back(do_tiles, a, b);
+    }
+    for (auto& th : pool) th.join();
+  }
+  for (const RemapTile& tile : plan.tiles) {
+    plan.max_rect_w = std::max(plan.max_rect_w, tile.w);
+    plan.max_rect_h = std::max(plan.max_rect_h, tile.h);
+    plan.max_lds_bytes = std::max(plan.max_lds_bytes, remap_tile_lds_bytes(tile.w, tile.h));
+  }
+  plan.valid = true;
 }
 
 // ---------------------------------------------------------------------------------------------

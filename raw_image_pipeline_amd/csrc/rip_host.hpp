@@ -131,6 +131,33 @@ void fisheye_init_undistort_rectify_map(const double K[9], const double D[4], co
                                         const double P[9], int w, int h, float* map_xy);
 
 // ---------------------------------------------------------------------------------------------
+// Compiled remap plan.  cv::remap(INTER_LINEAR) quantises every map entry to 1/32 px before
+// interpolating; the plan stores exactly that quantised form, organised in destination tiles of
+// kRemapTileW x kRemapTileH pixels whose source footprint (a rectangle) is staged in LDS by the
+// kernel.  Per destination pixel one 32-bit word: relx | rely << 11 | fx << 22 | fy << 27 with
+// (relx, rely) relative to the tile's source rectangle; kRemapOutside: the pixel maps entirely
+// outside the source (border constant 0); kRemapBorder: some taps fall outside -- the kernel
+// takes the per-tap path on the float map for it.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRemapTileW = 64, kRemapTileH = 16;
+constexpr uint32_t kRemapOutside = 0xFFFFFFFFu, kRemapBorder = 0xFFFFFFFEu;
+struct RemapTile {
+  int x0, y0, w, h;  // source rectangle in pixels (w == 0: no interior pixel in this tile)
+};
+struct RemapPlan {
+  int drows = 0, dcols = 0, src_rows = 0, src_cols = 0;
+  int tiles_x = 0, tiles_y = 0;
+  std::vector<uint32_t> words;   // tile-major: tile t occupies words[t*1024 .. t*1024+1023], row-major inside
+  std::vector<RemapTile> tiles;
+  int max_rect_w = 0, max_rect_h = 0;
+  size_t max_lds_bytes = 0;      // over tiles, for a source pixel size of 3 bytes
+  bool valid = false;
+};
+// LDS bytes the kernel needs for a source rectangle w x h of 3-byte pixels
+size_t remap_tile_lds_bytes(int w, int h);
+void compile_remap_plan(RemapPlan& plan, const float* map_xy, int drows, int dcols, int src_rows, int src_cols);
+
+// ---------------------------------------------------------------------------------------------
 // CCC model (convolutional_color_constancy.cpp:116-207)
 // ---------------------------------------------------------------------------------------------
 struct CccModel {

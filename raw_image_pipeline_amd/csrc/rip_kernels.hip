@@ -30,9 +30,14 @@ constexpr int kBlock = 256;
 // scalar helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sat_round_u8(float v) {
-  // saturate_cast<uchar>(float): round half to even, clamp (clamping first is equivalent)
-  v = __builtin_fminf(__builtin_fmaxf(v, 0.f), 255.f);
-  return (int)__builtin_rintf(v);
+  // saturate_cast<uchar>(float) = round half to even, clamp to [0,255], NaN -> 0: exactly
+  // v_cvt_pk_u8_f32 (checked on gfx950 by tools/probes/cvt_pk_u8_probe.hip)
+  return (int)__builtin_amdgcn_cvt_pk_u8_f32(v, 0, 0u);
+}
+// 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate).  Operands must fit 24 bits.
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ unsigned umulhi24(unsigned a, unsigned b) {
+  return (unsigned)(((unsigned long long)(a & 0xffffffu) * (unsigned long long)(b & 0xffffffu)) >> 32);
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
@@ -221,7 +226,7 @@ __device__ __forceinline__ void apply_cc(const ChainParams& p, int& b, int& g, i
 // vignetting mask value at destination pixel (row, col): vignetting_correction.cpp:32-63
 __device__ __forceinline__ float vignette_mask(const ChainParams& p, int row, int col) {
   int dx2 = 2 * col - p.dcols, dy2 = 2 * row - p.drows;
-  double s = (double)(dx2 * dx2 + dy2 * dy2) * 0.25;  // exact
+  double s = (double)(mul24(dx2, dx2) + mul24(dy2, dy2)) * 0.25;  // exact (|dx2|, |dy2| < 2^23)
   double s2 = s * s;
   double k = s * p.vig_a2 + s2 * p.vig_a4;
   float m = (float)k;
@@ -233,8 +238,16 @@ __device__ __forceinline__ float vignette_mask(const ChainParams& p, int row, in
 
 // abToXZ_b[i - minABvalue] (OpenCV color_lab.cpp initLabTabs), evaluated arithmetically
 __device__ __forceinline__ int ab_to_xz(int i) {
-  if (i <= 3390) return i * 108 / 841 - 290;  // BASE*16/116*108/841 == 290
-  return (((i * i) >> 14) * i) >> 14;
+  if (i <= 3390) {
+    // i*108/841 (C truncation) - 290, with BASE*16/116*108/841 == 290.  n = i*108 is in
+    // [-879660, 366120]; trunc(n/841) = floor((n + (n<0 ? 840 : 0)) / 841); the floor division is
+    // one v_mul_hi_u32_u24 by ceil(2^32/841) after biasing by 841*1100 (exact below 11.9e6).
+    int n = mul24(i, 108);
+    n += (n >> 31) & 840;
+    unsigned q = umulhi24((unsigned)(n + 841 * 1100), 5106977u);
+    return (int)q - (1100 + 290);
+  }
+  return mul24(mul24(i, i) >> 14, i) >> 14;  // i in (3390, 28719]: both products < 2^31
 }
 
 // BGR -> 8-bit Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93; RGB2Lab_b /
@@ -244,27 +257,26 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
                                                float mask, int& b, int& g, int& r) {
   constexpr int kShift2 = 15;
   int v0 = tb.lin(b), v1 = tb.lin(g), v2 = tb.lin(r);
-  int fX = tb.cbrt((v0 * fwd[0] + v1 * fwd[1] + v2 * fwd[2] + 2048) >> 12);
-  int fY = tb.cbrt((v0 * fwd[3] + v1 * fwd[4] + v2 * fwd[5] + 2048) >> 12);
-  int fZ = tb.cbrt((v0 * fwd[6] + v1 * fwd[7] + v2 * fwd[8] + 2048) >> 12);
+  int fX = tb.cbrt((mul24(v0, fwd[0]) + mul24(v1, fwd[1]) + mul24(v2, fwd[2]) + 2048) >> 12);
+  int fY = tb.cbrt((mul24(v0, fwd[3]) + mul24(v1, fwd[4]) + mul24(v2, fwd[5]) + 2048) >> 12);
+  int fZ = tb.cbrt((mul24(v0, fwd[6]) + mul24(v1, fwd[7]) + mul24(v2, fwd[8]) + 2048) >> 12);
   const int Lscale = (116 * 255 + 50) / 100;
   const int Lshift = -((16 * 255 * (1 << kShift2) + 50) / 100);
-  int L = (Lscale * fY + Lshift + (1 << 14)) >> kShift2;
-  int a = (500 * (fX - fY) + 128 * (1 << kShift2) + (1 << 14)) >> kShift2;
-  int bb = (200 * (fY - fZ) + 128 * (1 << kShift2) + (1 << 14)) >> kShift2;
-  L = clampi(L, 0, 255);
+  int L = (mul24(Lscale, fY) + (Lshift + (1 << 14))) >> kShift2;  // in [0,255] by construction
+  int a = (mul24(500, fX - fY) + (128 * (1 << kShift2) + (1 << 14))) >> kShift2;
+  int bb = (mul24(200, fY - fZ) + (128 * (1 << kShift2) + (1 << 14))) >> kShift2;
   a = clampi(a, 0, 255);
   bb = clampi(bb, 0, 255);
   L = sat_round_u8((float)L * mask);
   unsigned yf = tb.yf(L);
   int y = (int)(yf & 0xffffu), ify = (int)(yf >> 16);
-  int adiv = ((5 * a * 53687 + (1 << 7)) >> 13) - 128 * 16384 / 500;
-  int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
+  int adiv = ((mul24(a, 5 * 53687) + (1 << 7)) >> 13) - 128 * 16384 / 500;
+  int bdiv = ((mul24(bb, 41943) + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
   int x = ab_to_xz(ify + adiv);
   int z = ab_to_xz(ify - bdiv);
-  int bo = (inv[0] * x + inv[1] * y + inv[2] * z + (1 << 13)) >> 14;
-  int go = (inv[3] * x + inv[4] * y + inv[5] * z + (1 << 13)) >> 14;
-  int ro = (inv[6] * x + inv[7] * y + inv[8] * z + (1 << 13)) >> 14;
+  int bo = (mul24(inv[0], x) + mul24(inv[1], y) + mul24(inv[2], z) + (1 << 13)) >> 14;
+  int go = (mul24(inv[3], x) + mul24(inv[4], y) + mul24(inv[5], z) + (1 << 13)) >> 14;
+  int ro = (mul24(inv[6], x) + mul24(inv[7], y) + mul24(inv[8], z) + (1 << 13)) >> 14;
   b = tb.invg(clampi(bo, 0, 4095));
   g = tb.invg(clampi(go, 0, 4095));
   r = tb.invg(clampi(ro, 0, 4095));
@@ -276,7 +288,7 @@ template <typename Tabs>
 __device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, int& b, int& g, int& r) {
   int v = max(b, max(g, r)), vmin = min(b, min(g, r));
   int diff = v - vmin;
-  int s = (diff * tb.sdiv(v) + (1 << 11)) >> 12;
+  int s = (mul24(diff, tb.sdiv(v)) + (1 << 11)) >> 12;
   int h;
   if (v == r)
     h = g - b;
@@ -284,7 +296,7 @@ __device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, 
     h = b - r + 2 * diff;
   else
     h = r - g + 4 * diff;
-  h = (h * tb.hdiv(diff) + (1 << 11)) >> 12;
+  h = (mul24(h, tb.hdiv(diff)) + (1 << 11)) >> 12;
   h += h < 0 ? 180 : 0;
   h = clampi(h, 0, 255);
   int H = sat_round_u8((float)h * p.hsv_gain[0]);
@@ -392,17 +404,17 @@ struct Window {
   }
 };
 
-__device__ __forceinline__ void load_window(const uint8_t* frame, size_t step, int rows, int cols, int y0, int x0,
+__device__ __forceinline__ void load_window(const uint8_t* frame, unsigned step, int rows, int cols, int y0, int x0,
                                             Window& win) {
   const int xl = x0 >= 4 ? x0 - 4 : x0;
   const int xr = x0 + 4 < cols ? x0 + 4 : x0;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    int y = clampi(y0 - 1 + r, 0, rows - 1);
-    const uint8_t* row = frame + (size_t)y * step;
-    win.w[r][0] = *reinterpret_cast<const uint32_t*>(row + xl);
-    win.w[r][1] = *reinterpret_cast<const uint32_t*>(row + x0);
-    win.w[r][2] = *reinterpret_cast<const uint32_t*>(row + xr);
+    const int y = clampi(y0 - 1 + r, 0, rows - 1);
+    const unsigned row = __umul24((unsigned)y, step);  // 32-bit offsets: a frame is < 4 GiB, a row < 16 MiB
+    win.w[r][0] = *reinterpret_cast<const uint32_t*>(frame + (row + (unsigned)xl));
+    win.w[r][1] = *reinterpret_cast<const uint32_t*>(frame + (row + (unsigned)x0));
+    win.w[r][2] = *reinterpret_cast<const uint32_t*>(frame + (row + (unsigned)xr));
   }
 }
 
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
     im.split(item, pair, grp);
     const int y0 = pair * 2, x0 = grp * 4;
     Window win;
-    load_window(src, p.src_step, p.rows, p.cols, y0, x0, win);
+    load_window(src, (unsigned)p.src_step, p.rows, p.cols, y0, x0, win);
     int px[2][4][3];
     debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, px);
 #pragma unroll
@@ -556,11 +568,11 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
         for (int c = 0; c < 3; c++) q[k][c] = flip180 ? px[ly][3 - k][c] : px[ly][k][c];
         (void)lx;
       }
-      if (tap) store12(tap + ((size_t)yd * p.dcols + xbase) * 3, pack4(q));
+      if (tap) store12(tap + (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u, pack4(q));
 #pragma unroll
       for (int k = 0; k < 4; k++)
         pointwise<BITS>(p, w, tb, s_fwd, s_inv, yd, xbase + k, q[k][0], q[k][1], q[k][2]);
-      store12(dst + (size_t)yd * p.dst_step + (size_t)xbase * 3, pack4(q));
+      store12(dst + (__umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u), pack4(q));
     }
   }
 }
@@ -638,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, ItemM
     im.split(item, pair, grp);
     const int y0 = pair * 2, x0 = grp * 4;
     Window win;
-    load_window(src, p.src_step, p.rows, p.cols, y0, x0, win);
+    load_window(src, (unsigned)p.src_step, p.rows, p.cols, y0, x0, win);
     int px[2][4][3];
     debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, px);
 #pragma unroll
@@ -977,69 +989,209 @@ __device__ __forceinline__ int round_map(float v) {
   return (int)__builtin_rintf(s);
 }
 
+// Six consecutive source bytes starting at byte offset `off` of the frame (any alignment), fetched
+// as three aligned dwords (one global_load_dwordx3) and realigned with v_alignbyte_b32.
+// Requires off + 12 <= readable bytes (checked by the caller).
+__device__ __forceinline__ void load6(const uint8_t* frame, unsigned off, uint32_t& lo, uint32_t& hi) {
+  const uint3 v = *reinterpret_cast<const uint3*>(frame + (off & ~3u));
+  lo = __builtin_amdgcn_alignbyte(v.y, v.x, off & 3u);
+  hi = __builtin_amdgcn_alignbyte(v.z, v.y, off & 3u);
+}
+
+struct RemapSrc {
+  const uint8_t* frame;
+  unsigned step;      // bytes per row (< 2^24)
+  unsigned readable;  // bytes that may be read starting at `frame` (to the end of the batch buffer)
+  int rows, cols;
+  bool wide_ok;       // frame base is dword aligned: load6 may be used
+};
+
 template <int CN>
-__device__ __forceinline__ void remap_pixel(const uint8_t* src, size_t step, int rows, int cols, float mx, float my,
-                                            int (&out)[CN]) {
-  int sxq = round_map(mx), syq = round_map(my);
-  int sx = clampi(sxq >> 5, -32768, 32767), sy = clampi(syq >> 5, -32768, 32767);
-  int fx = sxq & 31, fy = syq & 31;
-  int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
-  if ((unsigned)sx < (unsigned)(cols - 1) && (unsigned)sy < (unsigned)(rows - 1)) {
-    const uint8_t* p0 = src + (size_t)sy * step + (size_t)sx * CN;
-    const uint8_t* p1 = p0 + step;
+__device__ __forceinline__ void remap_pixel(const RemapSrc& s, float mx, float my, int (&out)[CN]) {
+  const int sxq = round_map(mx), syq = round_map(my);
+  const int sx = clampi(sxq >> 5, -32768, 32767), sy = clampi(syq >> 5, -32768, 32767);
+  const int fx = sxq & 31, fy = syq & 31;
+  // cv::remap's Q15 bilinear weights 32(32-fx)(32-fy)...; separable form, exact in integers:
+  // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15 == (top*(32-fy) + bot*fy + 512) >> 10
+  const int wx1 = fx, wx0 = 32 - fx, wy1 = fy, wy0 = 32 - fy;
+  if ((unsigned)sx < (unsigned)(s.cols - 1) && (unsigned)sy < (unsigned)(s.rows - 1)) {
+    const unsigned off0 = __umul24((unsigned)sy, s.step) + (unsigned)sx * CN;
+    const unsigned off1 = off0 + s.step;
+    int p0[2 * CN], p1[2 * CN];
+    if (CN == 3 && s.wide_ok && off1 + 12u <= s.readable) {
+      uint32_t l0, h0, l1, h1;
+      load6(s.frame, off0, l0, h0);
+      load6(s.frame, off1, l1, h1);
+      p0[0] = l0 & 0xff; p0[1] = (l0 >> 8) & 0xff; p0[2] = (l0 >> 16) & 0xff; p0[3] = l0 >> 24; p0[4] = h0 & 0xff; p0[5] = (h0 >> 8) & 0xff;
+      p1[0] = l1 & 0xff; p1[1] = (l1 >> 8) & 0xff; p1[2] = (l1 >> 16) & 0xff; p1[3] = l1 >> 24; p1[4] = h1 & 0xff; p1[5] = (h1 >> 8) & 0xff;
+    } else {
 #pragma unroll
-    for (int c = 0; c < CN; c++)
-      out[c] = clampi((p0[c] * w00 + p0[CN + c] * w01 + p1[c] * w10 + p1[CN + c] * w11 + (1 << 14)) >> 15, 0, 255);
+      for (int k = 0; k < 2 * CN; k++) {
+        p0[k] = s.frame[off0 + k];
+        p1[k] = s.frame[off1 + k];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+      const int top = mul24(p0[c], wx0) + mul24(p0[CN + c], wx1);
+      const int bot = mul24(p1[c], wx0) + mul24(p1[CN + c], wx1);
+      out[c] = (mul24(top, wy0) + mul24(bot, wy1) + 512) >> 10;  // <= 255: convex combination
+    }
     return;
   }
-  if (sx >= cols || sx + 1 < 0 || sy >= rows || sy + 1 < 0) {
+  if (sx >= s.cols || sx + 1 < 0 || sy >= s.rows || sy + 1 < 0) {
 #pragma unroll
     for (int c = 0; c < CN; c++) out[c] = 0;
     return;
   }
-  bool x0 = sx >= 0 && sx < cols, x1 = sx + 1 >= 0 && sx + 1 < cols;
-  bool y0 = sy >= 0 && sy < rows, y1 = sy + 1 >= 0 && sy + 1 < rows;
+  // partially outside: taps beyond the image contribute the border constant 0
+  const bool x0 = sx >= 0 && sx < s.cols, x1 = sx + 1 >= 0 && sx + 1 < s.cols;
+  const bool y0 = sy >= 0 && sy < s.rows, y1 = sy + 1 >= 0 && sy + 1 < s.rows;
 #pragma unroll
   for (int c = 0; c < CN; c++) {
-    int p00 = (x0 && y0) ? src[(size_t)sy * step + (size_t)sx * CN + c] : 0;
-    int p01 = (x1 && y0) ? src[(size_t)sy * step + (size_t)(sx + 1) * CN + c] : 0;
-    int p10 = (x0 && y1) ? src[(size_t)(sy + 1) * step + (size_t)sx * CN + c] : 0;
-    int p11 = (x1 && y1) ? src[(size_t)(sy + 1) * step + (size_t)(sx + 1) * CN + c] : 0;
-    out[c] = clampi((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15, 0, 255);
+    const int p00 = (x0 && y0) ? s.frame[(size_t)sy * s.step + (size_t)sx * CN + c] : 0;
+    const int p01 = (x1 && y0) ? s.frame[(size_t)sy * s.step + (size_t)(sx + 1) * CN + c] : 0;
+    const int p10 = (x0 && y1) ? s.frame[(size_t)(sy + 1) * s.step + (size_t)sx * CN + c] : 0;
+    const int p11 = (x1 && y1) ? s.frame[(size_t)(sy + 1) * s.step + (size_t)(sx + 1) * CN + c] : 0;
+    out[c] = (mul24(mul24(p00, wx0) + mul24(p01, wx1), wy0) + mul24(mul24(p10, wx0) + mul24(p11, wx1), wy1) + 512) >> 10;
   }
+}
+
+__device__ __forceinline__ RemapSrc remap_src(const RemapParams& p, int frame) {
+  RemapSrc s;
+  s.frame = p.src + (size_t)frame * p.src_frame_stride;
+  s.step = (unsigned)p.src_step;
+  const unsigned long long rest = (unsigned long long)(p.n_frames - frame) * p.src_frame_stride;
+  s.readable = rest > 0xffffffffull ? 0xffffffffu : (unsigned)rest;
+  s.rows = p.rows;
+  s.cols = p.cols;
+  s.wide_ok = (reinterpret_cast<uintptr_t>(s.frame) & 3u) == 0;
+  return s;
 }
 
 // 4 destination pixels per thread (CN == 3, dcols % 4 == 0, dword-aligned pitch)
 __global__ __launch_bounds__(kBlock) void remap_vec4_kernel(RemapParams p, ItemMap im, int items_per_frame) {
   const int frame = blockIdx.y;
-  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  const RemapSrc s = remap_src(p, frame);
   uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
   for (int item = blockIdx.x * kBlock + threadIdx.x; item < items_per_frame; item += gridDim.x * kBlock) {
     int yd, grp;
     im.split(item, yd, grp);
     const int xd = grp * 4;
-    const float4* m = reinterpret_cast<const float4*>(p.map_xy + ((size_t)yd * p.dcols + xd) * 2);
-    float4 m0 = m[0], m1 = m[1];
+    const float4* m = reinterpret_cast<const float4*>(p.map_xy + ((size_t)(__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xd)) * 2);
+    const float4 m0 = m[0], m1 = m[1];
     int q[4][3];
-    remap_pixel<3>(src, p.src_step, p.rows, p.cols, m0.x, m0.y, q[0]);
-    remap_pixel<3>(src, p.src_step, p.rows, p.cols, m0.z, m0.w, q[1]);
-    remap_pixel<3>(src, p.src_step, p.rows, p.cols, m1.x, m1.y, q[2]);
-    remap_pixel<3>(src, p.src_step, p.rows, p.cols, m1.z, m1.w, q[3]);
-    store12(dst + (size_t)yd * p.dst_step + (size_t)xd * 3, pack4(q));
+    remap_pixel<3>(s, m0.x, m0.y, q[0]);
+    remap_pixel<3>(s, m0.z, m0.w, q[1]);
+    remap_pixel<3>(s, m1.x, m1.y, q[2]);
+    remap_pixel<3>(s, m1.z, m1.w, q[3]);
+    store12(dst + (__umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xd * 3u), pack4(q));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiled remap over a compiled plan: one workgroup = one 64x16 destination tile.  The tile's source
+// rectangle is copied into LDS with aligned 16-byte loads (every source byte crosses the memory
+// pipeline once per tile instead of once per tap), the taps are read back from LDS, and the
+// bilinear weights are applied with v_dot4_u32_u8.  The plan word (4 B/px) and the tile descriptor
+// are read once per tile and reused for every frame of the batch.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_load6(const uint8_t* lds, unsigned a, uint32_t& lo, uint32_t& hi) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(lds + (a & ~3u));
+  const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+  lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
+  hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+}
+
+__global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const RemapParams& b = p.base;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 4, lgrp = tid & 15;
+  const unsigned step = (unsigned)b.src_step;
+  for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
+    const int tile = xcd * per_xcd + ti;
+    if (tile >= ntiles) break;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const RemapTileDesc d = p.tiles[tile];
+    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * 1024)[tid];
+    const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
+    const int yd = ty * 16 + lrow, xd = tx * 64 + lgrp * 4;
+    const bool in_image = yd < b.drows && xd < b.dcols;
+    const unsigned xbyte0 = (unsigned)d.x0 * 3u;
+    const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
+    const unsigned pitch = ((unsigned)d.w * 3u + 15u + 12u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
+    const unsigned chunks = pitch >> 4;
+    const unsigned total = d.w > 0 ? chunks * (unsigned)d.h : 0u;
+    const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
+    for (int f = 0; f < b.n_frames; f++) {
+      const RemapSrc s = remap_src(b, f);
+      // ---- stage the source rectangle -----------------------------------------------------------
+      for (unsigned i = tid; i < total; i += kBlock) {
+        int r, c;
+        cm.split((int)i, r, c);
+        const unsigned off = __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (off + 16u <= s.readable) v = *reinterpret_cast<const uint4*>(s.frame + off);
+        *reinterpret_cast<uint4*>(lds + (__umul24((unsigned)r, pitch) + ((unsigned)c << 4))) = v;
+      }
+      __syncthreads();
+      // ---- gather -----------------------------------------------------------------------------------
+      if (in_image) {
+        int q[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t w = words[k];
+          if (w >= kPlanBorder) {
+            if (w == kPlanBorder) {
+              const float2 m = reinterpret_cast<const float2*>(b.map_xy)[__umul24((unsigned)yd, (unsigned)b.dcols) + (unsigned)(xd + k)];
+              remap_pixel<3>(s, m.x, m.y, q[k]);
+            } else {
+              q[k][0] = q[k][1] = q[k][2] = 0;
+            }
+            continue;
+          }
+          const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu;
+          const unsigned fx = (w >> 22) & 31u, fy = w >> 27;
+          const unsigned a = __umul24(rely, pitch) + relx * 3u + ph;
+          uint32_t t0, t1, b0, b1;  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
+          lds_load6(lds, a, t0, t1);
+          lds_load6(lds, a + pitch, b0, b1);
+          const unsigned wx0 = 32u - fx, wx1 = fx, wy0 = 32u - fy, wy1 = fy;
+          const unsigned wB = wx0 | (wx1 << 24), wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
+          const unsigned topB = __builtin_amdgcn_udot4(t0, wB, 0u, false);
+          const unsigned topG = __builtin_amdgcn_udot4(t0, wG0, __builtin_amdgcn_udot4(t1, wx1, 0u, false), false);
+          const unsigned topR = __builtin_amdgcn_udot4(t0, wR0, __builtin_amdgcn_udot4(t1, wR1, 0u, false), false);
+          const unsigned botB = __builtin_amdgcn_udot4(b0, wB, 0u, false);
+          const unsigned botG = __builtin_amdgcn_udot4(b0, wG0, __builtin_amdgcn_udot4(b1, wx1, 0u, false), false);
+          const unsigned botR = __builtin_amdgcn_udot4(b0, wR0, __builtin_amdgcn_udot4(b1, wR1, 0u, false), false);
+          // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15, exact
+          q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1) + 512u) >> 10);
+          q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1) + 512u) >> 10);
+          q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1) + 512u) >> 10);
+        }
+        uint8_t* dst = b.dst + (size_t)f * b.dst_frame_stride;
+        store12(dst + (__umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u), pack4(q));
+      }
+      __syncthreads();
+    }
   }
 }
 
 template <int CN>
 __global__ __launch_bounds__(kBlock) void remap_generic_kernel(RemapParams p) {
   const int frame = blockIdx.y;
-  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  const RemapSrc s = remap_src(p, frame);
   uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
   const long long npix = (long long)p.drows * p.dcols;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
     int yd = (int)(i / p.dcols), xd = (int)(i - (long long)yd * p.dcols);
     const float* m = p.map_xy + (size_t)i * 2;
     int o[CN];
-    remap_pixel<CN>(src, p.src_step, p.rows, p.cols, m[0], m[1], o);
+    remap_pixel<CN>(s, m[0], m[1], o);
     uint8_t* d = dst + (size_t)yd * p.dst_step + (size_t)xd * CN;
 #pragma unroll
     for (int c = 0; c < CN; c++) d[c] = (uint8_t)o[c];
@@ -1060,7 +1212,8 @@ bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0
 
 bool bayer_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, int rows, int cols, int kind) {
   return kind == SRC_BAYER && cols % 4 == 0 && rows % 2 == 0 && rows >= 4 && cols >= 4 && step % 4 == 0 &&
-         frame_stride % 4 == 0 && aligned4(src);
+         frame_stride % 4 == 0 && aligned4(src) && step < (1u << 24) && rows < (1 << 23) &&
+         (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
 }
 
 template <int BITS>
@@ -1073,6 +1226,7 @@ void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, 
 int chain_uses_fast_path(const ChainParams& p) {
   return bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
          (p.flip_angle == 0 || p.flip_angle == 180) && p.channels == 3 && p.dst_step % 4 == 0 &&
+         p.dst_step < (1u << 24) && (unsigned long long)p.dst_step * (unsigned long long)p.drows < (1ull << 32) &&
          p.dst_frame_stride % 4 == 0 && aligned4(p.dst) && (!p.tap || (aligned4(p.tap) && p.tap_frame_stride % 4 == 0));
 }
 
@@ -1134,8 +1288,32 @@ void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax
   }
 }
 
+bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
+  const RemapParams& b = p.base;
+  if (b.n_frames <= 0) return true;
+  const bool ok = b.channels == 3 && b.dcols % 4 == 0 && b.dst_step % 4 == 0 && b.dst_frame_stride % 4 == 0 && aligned4(b.dst) &&
+                  b.src_step % 16 == 0 && b.src_frame_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(b.src) & 15u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p.words) & 15u) == 0 && b.src_step < (1u << 24) && b.rows < (1 << 23) &&
+                  (unsigned long long)b.src_step * (unsigned long long)b.rows < (1ull << 32) && b.dst_step < (1u << 24) &&
+                  (unsigned long long)b.dst_step * (unsigned long long)b.drows < (1ull << 32) && p.lds_bytes <= 64u * 1024u &&
+                  p.tiles_x * 64 >= b.dcols && p.tiles_y * 16 >= b.drows;
+  if (!ok) return false;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  // persistent workgroups, a multiple of 8 (one share of the tile range per XCD); LDS bounds residency
+  const unsigned lds = std::max(p.lds_bytes, 16u);
+  const int per_cu = std::max(1, std::min(8, (int)((160u * 1024u) / (lds + 256u))));
+  int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
+  blocks = std::max(8, blocks / 8 * 8);
+  hipLaunchKernelGGL(remap_tiled_kernel, dim3(blocks), dim3(kBlock), lds, stream, p);
+  return true;
+}
+
 void launch_remap(const RemapParams& p, hipStream_t stream) {
   if (p.n_frames <= 0) return;
+  // remap_pixel addresses a source frame with 32-bit offsets and 24-bit multiplies
+  if (p.src_step >= (1u << 24) || p.rows >= (1 << 23) || (unsigned long long)p.src_step * (unsigned long long)p.rows >= (1ull << 32) ||
+      p.dst_step >= (1u << 24) || (unsigned long long)p.dst_step * (unsigned long long)p.drows >= (1ull << 32))
+    return;  // rejected by the API layer before we get here (see rip_api.cpp make_plan)
   const bool vec = p.channels == 3 && p.dcols % 4 == 0 && p.dst_step % 4 == 0 && p.dst_frame_stride % 4 == 0 &&
                    aligned4(p.dst) && (reinterpret_cast<uintptr_t>(p.map_xy) & 15u) == 0;
   if (vec) {

@@ -136,7 +136,23 @@ struct RemapParams {
   int n_frames;
 };
 
+// Tiled remap over a compiled plan (rip_host.hpp RemapPlan): 64x16 destination tiles, source
+// rectangle staged in LDS, 4 B/px plan word instead of the 8 B/px float2 map.
+constexpr uint32_t kPlanOutside = 0xFFFFFFFFu, kPlanBorder = 0xFFFFFFFEu;  // == rip_host.hpp kRemap*
+struct RemapTileDesc {
+  int x0, y0, w, h;
+};
+struct RemapTiledParams {
+  RemapParams base;            // src/dst geometry; base.map_xy is used for border pixels only
+  const uint32_t* words;       // [tiles][1024]
+  const RemapTileDesc* tiles;  // [tiles_y * tiles_x]
+  int tiles_x, tiles_y;
+  unsigned lds_bytes;          // dynamic LDS per workgroup (>= max over tiles)
+};
+
 // ---- launchers (asynchronous on `stream`) -------------------------------------------------------
+// Returns false (and launches nothing) when the geometry does not qualify for the tiled kernel.
+bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream);
 void launch_chain(const ChainParams& p, hipStream_t stream);
 void launch_stats(const StatsParams& p, hipStream_t stream);
 void launch_ccc_estimate(const CccParams& p, hipStream_t stream);
