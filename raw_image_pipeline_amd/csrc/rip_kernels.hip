@@ -129,6 +129,7 @@ struct GlobalTabs {
   __device__ __forceinline__ int invg(int i) const { return t->inv_gamma[i]; }
   __device__ __forceinline__ int sdiv(int i) const { return t->sdiv[i]; }
   __device__ __forceinline__ int hdiv(int i) const { return t->hdiv[i]; }
+  __device__ __forceinline__ int xz(int i) const { return t->xz_tab[i + 8145]; }
 };
 
 template <bool ON, typename T, int N>
@@ -153,6 +154,8 @@ struct LdsTabs {
   LdsArr<kVig, uint8_t, 4096> invg_;
   LdsArr<kHsv, int32_t, 256> sdiv_;
   LdsArr<kHsv, int32_t, 256> hdiv_;
+  const int32_t* xz_;  // abToXZ_b stays in HBM/L2 (147 KB): gathered through the vector L1
+  __device__ __forceinline__ int xz(int i) const { return xz_[i + 8145]; }
   __device__ __forceinline__ int gamma(int i) const { return gamma_.v[i]; }
   __device__ __forceinline__ int lin(int i) const { return lin_.v[i]; }
   __device__ __forceinline__ int cbrt(int i) const { return cbrt_.v[i]; }
@@ -169,6 +172,7 @@ struct LdsTabs {
     for (int i = threadIdx.x; i < (int)(N * sizeof(T) / 4); i += kBlock) d[i] = s[i];
   }
   __device__ __forceinline__ void load(const DevTables* t) {
+    if (threadIdx.x == 0) xz_ = t->xz_tab;
     if constexpr (kGamma) copy(gamma_.v, t->gamma_lut);
     if constexpr (kVig) {
       copy(lin_.v, t->lin_tab);
@@ -257,9 +261,10 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
                                                float mask, int& b, int& g, int& r) {
   constexpr int kShift2 = 15;
   int v0 = tb.lin(b), v1 = tb.lin(g), v2 = tb.lin(r);
-  int fX = tb.cbrt((mul24(v0, fwd[0]) + mul24(v1, fwd[1]) + mul24(v2, fwd[2]) + 2048) >> 12);
-  int fY = tb.cbrt((mul24(v0, fwd[3]) + mul24(v1, fwd[4]) + mul24(v2, fwd[5]) + 2048) >> 12);
-  int fZ = tb.cbrt((mul24(v0, fwd[6]) + mul24(v1, fwd[7]) + mul24(v2, fwd[8]) + 2048) >> 12);
+  // nested form -> v_mad_i32_i24 chains (3 instructions per sum)
+  int fX = tb.cbrt((mul24(v2, fwd[2]) + (mul24(v1, fwd[1]) + (mul24(v0, fwd[0]) + 2048))) >> 12);
+  int fY = tb.cbrt((mul24(v2, fwd[5]) + (mul24(v1, fwd[4]) + (mul24(v0, fwd[3]) + 2048))) >> 12);
+  int fZ = tb.cbrt((mul24(v2, fwd[8]) + (mul24(v1, fwd[7]) + (mul24(v0, fwd[6]) + 2048))) >> 12);
   const int Lscale = (116 * 255 + 50) / 100;
   const int Lshift = -((16 * 255 * (1 << kShift2) + 50) / 100);
   int L = (mul24(Lscale, fY) + (Lshift + (1 << 14))) >> kShift2;  // in [0,255] by construction
@@ -272,11 +277,17 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
   int y = (int)(yf & 0xffffu), ify = (int)(yf >> 16);
   int adiv = ((mul24(a, 5 * 53687) + (1 << 7)) >> 13) - 128 * 16384 / 500;
   int bdiv = ((mul24(bb, 41943) + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
-  int x = ab_to_xz(ify + adiv);
-  int z = ab_to_xz(ify - bdiv);
-  int bo = (mul24(inv[0], x) + mul24(inv[1], y) + mul24(inv[2], z) + (1 << 13)) >> 14;
-  int go = (mul24(inv[3], x) + mul24(inv[4], y) + mul24(inv[5], z) + (1 << 13)) >> 14;
-  int ro = (mul24(inv[6], x) + mul24(inv[7], y) + mul24(inv[8], z) + (1 << 13)) >> 14;
+  int x, z;
+  if (p.xz_from_table) {
+    x = tb.xz(ify + adiv);
+    z = tb.xz(ify - bdiv);
+  } else {
+    x = ab_to_xz(ify + adiv);
+    z = ab_to_xz(ify - bdiv);
+  }
+  int bo = (mul24(inv[2], z) + (mul24(inv[1], y) + (mul24(inv[0], x) + (1 << 13)))) >> 14;
+  int go = (mul24(inv[5], z) + (mul24(inv[4], y) + (mul24(inv[3], x) + (1 << 13)))) >> 14;
+  int ro = (mul24(inv[8], z) + (mul24(inv[7], y) + (mul24(inv[6], x) + (1 << 13)))) >> 14;
   b = tb.invg(clampi(bo, 0, 4095));
   g = tb.invg(clampi(go, 0, 4095));
   r = tb.invg(clampi(ro, 0, 4095));
@@ -334,15 +345,15 @@ __device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, 
 }
 
 // The pointwise chain after flip.  BITS >= 0: compile-time stage set; BITS < 0: runtime.
-template <int BITS, typename Tabs>
+template <int BITS, int WB, typename Tabs>
 __device__ __forceinline__ void pointwise(const ChainParams& p, const FrameWb& w, const Tabs& tb, const int* fwd,
-                                          const int* inv, int yd, int xd, int& b, int& g, int& r) {
+                                          const int* inv, float mask, int& b, int& g, int& r) {
   const int bits = BITS >= 0 ? BITS : p.stage_bits;
-  apply_wb(p.wb_mode, w, b, g, r);
+  apply_wb(WB >= 0 ? WB : p.wb_mode, w, b, g, r);
   if (bits & ST_CC) apply_cc(p, b, g, r);
   if (bits & ST_VIG) {
     // gamma folded into lin_tab by the host
-    apply_vignette(p, tb, fwd, inv, vignette_mask(p, yd, xd), b, g, r);
+    apply_vignette(p, tb, fwd, inv, mask, b, g, r);
   } else if (bits & ST_GAMMA) {
     b = tb.gamma(b);
     g = tb.gamma(g);
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
       t[1] = (uint8_t)g;
       t[2] = (uint8_t)r;
     }
-    pointwise<-1>(p, w, tb, p.tabs->lab_fwd, p.tabs->lab_inv, yd, xd, b, g, r);
+    pointwise<-1, -1>(p, w, tb, p.tabs->lab_fwd, p.tabs->lab_inv, (p.stage_bits & ST_VIG) ? vignette_mask(p, yd, xd) : 1.0f, b, g, r);
     uint8_t* o = dst + (size_t)yd * p.dst_step + (size_t)xd * 3;
     o[0] = (uint8_t)b;
     o[1] = (uint8_t)g;
@@ -418,66 +429,93 @@ __device__ __forceinline__ void load_window(const uint8_t* frame, unsigned step,
   }
 }
 
-// px[ly][lx][c], c = 0:B 1:G 2:R.  RY/RX: position of the R sample in the 2x2 cell.
+// Four pixels of one image row as planar byte vectors: byte j of .b/.g/.r = pixel j.
+struct Planar {
+  uint32_t b, g, r;
+};
+__device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// Bilinear demosaic of the 4x2 tile, four pixels per instruction (SWAR): every row of the window is
+// split into its even and odd bytes, widened to 16-bit lanes inside a dword, so one v_add_u32 adds
+// two taps of two pixels and the sums (<= 4*255 + 2) cannot carry across lanes.
+// RY/RX: position of the R sample in the 2x2 cell.  out[ly] = image row y0 + ly.
 template <int RY, int RX>
-__device__ __forceinline__ void debayer_tile(const Window& win, int (&px)[2][4][3]) {
+__device__ __forceinline__ void debayer_swar(const Window& win, Planar (&out)[2]) {
+  constexpr uint32_t M8 = 0x00FF00FFu;
+  uint32_t hs_lo[4], hs_hi[4], c_lo[4], c_hi[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t wm = __builtin_amdgcn_alignbyte(win.w[r][1], win.w[r][0], 3);  // columns x0-1 .. x0+2
+    const uint32_t wp = __builtin_amdgcn_alignbyte(win.w[r][2], win.w[r][1], 1);  // columns x0+1 .. x0+4
+    hs_lo[r] = (wm & M8) + (wp & M8);  // left + right neighbour, pixels 0 and 2
+    hs_hi[r] = ((wm >> 8) & M8) + ((wp >> 8) & M8);  // pixels 1 and 3
+    c_lo[r] = win.w[r][1] & M8;
+    c_hi[r] = (win.w[r][1] >> 8) & M8;
+  }
+  constexpr uint32_t kEven = RX == 0 ? 0x00FF00FFu : 0xFF00FF00u;  // byte lanes with dx == 0
 #pragma unroll
   for (int ly = 0; ly < 2; ly++) {
     const int cr = ly + 1;
-#pragma unroll
-    for (int lx = 0; lx < 4; lx++) {
-      const int dy = (ly ^ RY) & 1, dx = (lx ^ RX) & 1;
-      const int c = win.at(cr, lx);
-      if (dy != dx) {
-        int h = (win.at(cr, lx - 1) + win.at(cr, lx + 1) + 1) >> 1;
-        int v = (win.at(cr - 1, lx) + win.at(cr + 1, lx) + 1) >> 1;
-        px[ly][lx][1] = c;
-        px[ly][lx][dy == 0 ? 2 : 0] = h;
-        px[ly][lx][dy == 0 ? 0 : 2] = v;
-      } else {
-        int x4 = (win.at(cr, lx - 1) + win.at(cr, lx + 1) + win.at(cr - 1, lx) + win.at(cr + 1, lx) + 2) >> 2;
-        int d4 = (win.at(cr - 1, lx - 1) + win.at(cr - 1, lx + 1) + win.at(cr + 1, lx - 1) + win.at(cr + 1, lx + 1) + 2) >> 2;
-        px[ly][lx][1] = x4;
-        px[ly][lx][dy == 0 ? 2 : 0] = c;
-        px[ly][lx][dy == 0 ? 0 : 2] = d4;
-      }
+    const uint32_t H = (((hs_lo[cr] + 0x00010001u) >> 1) & M8) | ((((hs_hi[cr] + 0x00010001u) >> 1) & M8) << 8);
+    const uint32_t V = (((c_lo[cr - 1] + c_lo[cr + 1] + 0x00010001u) >> 1) & M8) |
+                       ((((c_hi[cr - 1] + c_hi[cr + 1] + 0x00010001u) >> 1) & M8) << 8);
+    const uint32_t X4 = (((hs_lo[cr] + c_lo[cr - 1] + c_lo[cr + 1] + 0x00020002u) >> 2) & M8) |
+                        ((((hs_hi[cr] + c_hi[cr - 1] + c_hi[cr + 1] + 0x00020002u) >> 2) & M8) << 8);
+    const uint32_t D4 = (((hs_lo[cr - 1] + hs_lo[cr + 1] + 0x00020002u) >> 2) & M8) |
+                        ((((hs_hi[cr - 1] + hs_hi[cr + 1] + 0x00020002u) >> 2) & M8) << 8);
+    const uint32_t C = win.w[cr][1];
+    if (((ly ^ RY) & 1) == 0) {
+      // red row: dx == 0 -> R site (B = diag, G = cross, R = centre); dx == 1 -> G site (B = vert, R = horiz)
+      out[ly].b = bfi32(kEven, D4, V);
+      out[ly].g = bfi32(kEven, X4, C);
+      out[ly].r = bfi32(kEven, C, H);
+    } else {
+      // blue row: dx == 0 -> G site (B = horiz, R = vert); dx == 1 -> B site (B = centre, G = cross, R = diag)
+      out[ly].b = bfi32(kEven, H, C);
+      out[ly].g = bfi32(kEven, C, X4);
+      out[ly].r = bfi32(kEven, V, D4);
     }
   }
 }
 
-// demosaic of the 4x2 tile at (y0, x0) including OpenCV's border replication
+// demosaic of the 4x2 tile at (y0, x0) including OpenCV's border replication (column 0 := column 1,
+// column W-1 := W-2, then row 0 := row 1, row H-1 := H-2)
 __device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int rx, int y0, int x0, int rows, int cols,
-                                                 int (&px)[2][4][3]) {
+                                                 Planar (&out)[2]) {
   switch (ry * 2 + rx) {
-    case 0: debayer_tile<0, 0>(win, px); break;
-    case 1: debayer_tile<0, 1>(win, px); break;
-    case 2: debayer_tile<1, 0>(win, px); break;
-    default: debayer_tile<1, 1>(win, px); break;
+    case 0: debayer_swar<0, 0>(win, out); break;
+    case 1: debayer_swar<0, 1>(win, out); break;
+    case 2: debayer_swar<1, 0>(win, out); break;
+    default: debayer_swar<1, 1>(win, out); break;
   }
   if (x0 == 0) {
 #pragma unroll
-    for (int ly = 0; ly < 2; ly++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) px[ly][0][c] = px[ly][1][c];
+    for (int ly = 0; ly < 2; ly++) {
+      out[ly].b = (out[ly].b & 0xFFFFFF00u) | ((out[ly].b >> 8) & 0xFFu);
+      out[ly].g = (out[ly].g & 0xFFFFFF00u) | ((out[ly].g >> 8) & 0xFFu);
+      out[ly].r = (out[ly].r & 0xFFFFFF00u) | ((out[ly].r >> 8) & 0xFFu);
+    }
   }
   if (x0 + 4 == cols) {
 #pragma unroll
-    for (int ly = 0; ly < 2; ly++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) px[ly][3][c] = px[ly][2][c];
+    for (int ly = 0; ly < 2; ly++) {
+      out[ly].b = (out[ly].b & 0x00FFFFFFu) | ((out[ly].b << 8) & 0xFF000000u);
+      out[ly].g = (out[ly].g & 0x00FFFFFFu) | ((out[ly].g << 8) & 0xFF000000u);
+      out[ly].r = (out[ly].r & 0x00FFFFFFu) | ((out[ly].r << 8) & 0xFF000000u);
+    }
   }
-  if (y0 == 0) {
-#pragma unroll
-    for (int lx = 0; lx < 4; lx++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) px[0][lx][c] = px[1][lx][c];
-  }
-  if (y0 + 2 == rows) {
-#pragma unroll
-    for (int lx = 0; lx < 4; lx++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) px[1][lx][c] = px[0][lx][c];
-  }
+  if (y0 == 0) out[0] = out[1];
+  if (y0 + 2 == rows) out[1] = out[0];
+}
+
+// planar -> interleaved BGR (12 bytes) with six v_perm_b32
+__device__ __forceinline__ void interleave4(const Planar& v, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
+  const uint32_t bg01 = __builtin_amdgcn_perm(v.g, v.b, 0x05010400u);  // B0 G0 B1 G1
+  const uint32_t bg23 = __builtin_amdgcn_perm(v.g, v.b, 0x07030602u);  // B2 G2 B3 G3
+  d0 = __builtin_amdgcn_perm(v.r, bg01, 0x02040100u);                  // B0 G0 R0 B1
+  const uint32_t g1r1 = __builtin_amdgcn_perm(v.r, bg01, 0x00000503u); // G1 R1 . .
+  d1 = __builtin_amdgcn_perm(bg23, g1r1, 0x05040100u);                 // G1 R1 B2 G2
+  d2 = __builtin_amdgcn_perm(v.r, bg23, 0x07030206u);                  // R2 B3 G3 R3
 }
 
 struct Pack3 {
@@ -518,7 +556,7 @@ struct ItemMap {
   }
 };
 
-template <int BITS>
+template <int BITS, int WB>
 __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
   __shared__ LdsTabs<BITS> tb;
   __shared__ int s_fwd[9], s_inv[9];
@@ -531,48 +569,68 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
   // Persistent workgroups: the LDS tables are loaded once and amortised over many chunks of
   // kBlock items.  Block b runs on XCD b % 8 (observed dispatch order; speed only), so each
   // XCD walks its own contiguous range of chunks and vertically adjacent row pairs -- which
-  // share two halo rows -- hit the same L2.
+  // share two halo rows -- hit the same L2.  Frames are the innermost loop: everything that
+  // depends only on the position (item split, vignetting mask in FP64, addresses) is computed
+  // once per item and reused for every frame of the batch.
   const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
-  const int total_chunks = chunks_per_frame * p.n_frames;
-  const int per_xcd = (total_chunks + 7) / 8;
+  const int per_xcd = (chunks_per_frame + 7) / 8;
   const int xcd = blockIdx.x & 7;
   const bool flip180 = p.flip_angle == 180;
   for (int ci = blockIdx.x >> 3; ci < per_xcd; ci += gridDim.x >> 3) {
     const int chunk = xcd * per_xcd + ci;
-    if (chunk >= total_chunks) break;
-    const int frame = chunk / chunks_per_frame;
-    const int item = (chunk - frame * chunks_per_frame) * kBlock + threadIdx.x;
+    if (chunk >= chunks_per_frame) break;
+    const int item = chunk * kBlock + threadIdx.x;
     if (item >= items_per_frame) continue;
-    const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
-    uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
-    uint8_t* tap = p.tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr;
-    FrameWb w;
-    if (p.wb_mode != WB_NONE) w = p.wb[frame];
     int pair, grp;
     im.split(item, pair, grp);
     const int y0 = pair * 2, x0 = grp * 4;
-    Window win;
-    load_window(src, (unsigned)p.src_step, p.rows, p.cols, y0, x0, win);
-    int px[2][4][3];
-    debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, px);
+    const int xbase = flip180 ? p.cols - 4 - x0 : x0;
+    float mask[2][4];
+    unsigned dst_off[2], tap_off[2];
 #pragma unroll
     for (int ly = 0; ly < 2; ly++) {
-      const int ys = y0 + ly;
-      const int yd = flip180 ? p.rows - 1 - ys : ys;
-      const int xbase = flip180 ? p.cols - 4 - x0 : x0;
-      int q[4][3];
+      const int yd = flip180 ? p.rows - 1 - (y0 + ly) : y0 + ly;
+      dst_off[ly] = __umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u;
+      tap_off[ly] = (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int lx = flip180 ? 3 - k : k;  // k-th destination pixel of the group
+      for (int k = 0; k < 4; k++) mask[ly][k] = (BITS & ST_VIG) ? vignette_mask(p, yd, xbase + k) : 1.0f;
+    }
+    for (int frame = 0; frame < p.n_frames; frame++) {
+      const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+      uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+      uint8_t* tap = p.tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr;
+      FrameWb w;
+      if (WB != WB_NONE) w = p.wb[frame];
+      Window win;
+      load_window(src, (unsigned)p.src_step, p.rows, p.cols, y0, x0, win);
+      Planar rowpx[2];
+      debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
 #pragma unroll
-        for (int c = 0; c < 3; c++) q[k][c] = flip180 ? px[ly][3 - k][c] : px[ly][k][c];
-        (void)lx;
+      for (int ly = 0; ly < 2; ly++) {
+        Planar v = rowpx[ly];
+        if (flip180) {  // the group is written mirrored: reverse the four pixels
+          v.b = __builtin_bswap32(v.b);
+          v.g = __builtin_bswap32(v.g);
+          v.r = __builtin_bswap32(v.r);
+        }
+        Pack3 raw;
+        const bool need_raw = tap != nullptr || (BITS == 0 && WB == WB_NONE);
+        if (need_raw) interleave4(v, raw.a, raw.b, raw.c);
+        if (tap) store12(tap + tap_off[ly], raw);
+        if (BITS == 0 && WB == WB_NONE) {
+          store12(dst + dst_off[ly], raw);  // pure demosaic: no per-pixel stage
+          continue;
+        }
+        int q[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          q[k][0] = (int)((v.b >> (8 * k)) & 0xFFu);
+          q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
+          q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
+          pointwise<BITS, WB>(p, w, tb, s_fwd, s_inv, mask[ly][k], q[k][0], q[k][1], q[k][2]);
+        }
+        store12(dst + dst_off[ly], pack4(q));
       }
-      if (tap) store12(tap + (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u, pack4(q));
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        pointwise<BITS>(p, w, tb, s_fwd, s_inv, yd, xbase + k, q[k][0], q[k][1], q[k][2]);
-      store12(dst + (__umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u), pack4(q));
     }
   }
 }
@@ -651,12 +709,14 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, ItemM
     const int y0 = pair * 2, x0 = grp * 4;
     Window win;
     load_window(src, (unsigned)p.src_step, p.rows, p.cols, y0, x0, win);
-    int px[2][4][3];
-    debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, px);
+    Planar rowpx[2];
+    debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
 #pragma unroll
     for (int ly = 0; ly < 2; ly++)
 #pragma unroll
-      for (int lx = 0; lx < 4; lx++) stat_add(p, px[ly][lx][0], px[ly][lx][1], px[ly][lx][2], a);
+      for (int lx = 0; lx < 4; lx++)
+        stat_add(p, (int)((rowpx[ly].b >> (8 * lx)) & 0xFFu), (int)((rowpx[ly].g >> (8 * lx)) & 0xFFu),
+                 (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a);
   }
   stat_flush(p, a, p.stats + frame);
 }
@@ -1216,9 +1276,19 @@ bool bayer_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, i
          (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
 }
 
-template <int BITS>
+template <int BITS, int WB>
 void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(chain_fast_kernel<BITS>, grid, dim3(kBlock), 0, stream, p, im, items);
+  hipLaunchKernelGGL((chain_fast_kernel<BITS, WB>), grid, dim3(kBlock), 0, stream, p, im, items);
+}
+
+template <int BITS>
+void launch_fast_wb(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
+  switch (p.wb_mode) {
+    case WB_Q8: launch_fast<BITS, WB_Q8>(p, im, items, grid, stream); break;
+    case WB_FLOAT: launch_fast<BITS, WB_FLOAT>(p, im, items, grid, stream); break;
+    case WB_PCA: launch_fast<BITS, WB_PCA>(p, im, items, grid, stream); break;
+    default: launch_fast<BITS, WB_NONE>(p, im, items, grid, stream); break;
+  }
 }
 
 }  // namespace
@@ -1235,12 +1305,12 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
   if (chain_uses_fast_path(p)) {
     ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
     const int items = (p.rows / 2) * (p.cols / 4);
-    const long long chunks = (long long)((items + kBlock - 1) / kBlock) * p.n_frames;
+    const long long chunks = (long long)((items + kBlock - 1) / kBlock);
     // persistent grid: at most 256 CUs x 8 workgroups, a multiple of 8 (one share per XCD)
     int blocks = (int)std::min<long long>(2048, (chunks + 7) / 8 * 8);
     dim3 grid(blocks);
     switch (p.stage_bits & 15) {
-#define RIP_CASE(B) case B: launch_fast<B>(p, im, items, grid, stream); break;
+#define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream); break;
       RIP_CASE(0) RIP_CASE(1) RIP_CASE(2) RIP_CASE(3) RIP_CASE(4) RIP_CASE(5) RIP_CASE(6) RIP_CASE(7)
       RIP_CASE(8) RIP_CASE(9) RIP_CASE(10) RIP_CASE(11) RIP_CASE(12) RIP_CASE(13) RIP_CASE(14) RIP_CASE(15)
 #undef RIP_CASE
