@@ -130,7 +130,6 @@ struct rip_pipeline {
   DevBuf d_plan_words, d_plan_tiles;
   bool plan_uploaded = false;
   bool use_tiled_remap = true;
-  bool xz_from_table = false;
   int last_batch_frames = 0;
   // optional per-kernel timing with HIP events on the handle's stream (bench.py roofline leg)
   bool prof_on = false;
@@ -249,8 +248,6 @@ void ensure_tables(rip_pipeline* p) {
   std::memcpy(t.hdiv, c.hdiv180, sizeof(t.hdiv));
   std::memcpy(t.lab_fwd, c.fwd, sizeof(t.lab_fwd));
   std::memcpy(t.lab_inv, c.inv, sizeof(t.lab_inv));
-  for (int i = -8145; i <= 28719; i++)  // abToXZ_b (color_lab.cpp initLabTabs), integer arithmetic as published
-    t.xz_tab[i + 8145] = i <= 3390 ? i * 108 / 841 - 16384 * 16 / 116 * 108 / 841 : i * i / 16384 * i / 16384;
   std::vector<float> accum;
   rip::ccc_build_scalar_tables(t.log_tab, accum, t.exp_neg_tab);
   rip::fft256_twiddles(t.tw_re, t.tw_im);
@@ -568,7 +565,6 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   c.hsv_gain[1] = (float)p->m.ce_saturation_gain;
   c.hsv_gain[2] = (float)p->m.ce_value_gain;
   c.tabs = p->d_tabs.as<rip::DevTables>();
-  c.xz_from_table = p->xz_from_table ? 1 : 0;
   {
     ProfScope ps(p, RIP_KERNEL_CHAIN);
     rip::launch_chain(c, p->stream);
@@ -707,7 +703,6 @@ rip_status rip_create(int device, int use_gpu, const char* params_path, const ch
     }
     und_init(p);
     if (const char* t = std::getenv("RIP_REMAP_TILED")) p->use_tiled_remap = std::atoi(t) != 0;
-    if (const char* t = std::getenv("RIP_XZ_TABLE")) p->xz_from_table = std::atoi(t) != 0;
     const char* env = std::getenv("RIP_CCC_MODEL");
     if (env && *env) rip::ccc_load_model_file(p->ccc, env);
     *out = p;

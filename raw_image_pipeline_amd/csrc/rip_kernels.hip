@@ -36,6 +36,12 @@ __device__ __forceinline__ int sat_round_u8(float v) {
 }
 // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate).  Operands must fit 24 bits.
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+// a*b + c as ONE v_mad_i32_i24 (hipcc otherwise splits multiply-add chains into mul, mul, mad, add3)
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ unsigned umulhi24(unsigned a, unsigned b) {
   return (unsigned)(((unsigned long long)(a & 0xffffffu) * (unsigned long long)(b & 0xffffffu)) >> 32);
 }
@@ -123,13 +129,13 @@ __device__ __forceinline__ void unflip(int angle, int rows, int cols, int yd, in
 struct GlobalTabs {
   const DevTables* t;
   __device__ __forceinline__ int gamma(int i) const { return t->gamma_lut[i]; }
-  __device__ __forceinline__ int lin(int i) const { return t->lin_tab[i]; }
-  __device__ __forceinline__ int cbrt(int i) const { return t->cbrt_tab[i]; }
+
   __device__ __forceinline__ unsigned yf(int i) const { return t->yf_tab[i]; }
   __device__ __forceinline__ int invg(int i) const { return t->inv_gamma[i]; }
   __device__ __forceinline__ int sdiv(int i) const { return t->sdiv[i]; }
   __device__ __forceinline__ int hdiv(int i) const { return t->hdiv[i]; }
-  __device__ __forceinline__ int xz(int i) const { return t->xz_tab[i + 8145]; }
+  __device__ __forceinline__ float linf(int i) const { return (float)t->lin_tab[i]; }
+  __device__ __forceinline__ float cbrtf(unsigned i) const { return (float)t->cbrt_tab[i]; }
 };
 
 template <bool ON, typename T, int N>
@@ -148,17 +154,15 @@ struct LdsTabs {
   // gamma bytes are only needed when the gamma result itself is consumed (not folded into lin_tab)
   static constexpr bool kGamma = (BITS & ST_GAMMA) != 0 && !kVig;
   LdsArr<kGamma, uint8_t, 256> gamma_;
-  LdsArr<kVig, uint16_t, 256> lin_;
-  LdsArr<kVig, uint16_t, 3072> cbrt_;
+  LdsArr<kVig, float, 256> lin_;    // exact small integers held as float: the Lab forward sums run
+  LdsArr<kVig, float, 3072> cbrt_;  // on v_fma_f32 (2 cycles) instead of v_mad_i32_i24 (4 cycles)
   LdsArr<kVig, uint32_t, 256> yf_;
   LdsArr<kVig, uint8_t, 4096> invg_;
   LdsArr<kHsv, int32_t, 256> sdiv_;
   LdsArr<kHsv, int32_t, 256> hdiv_;
-  const int32_t* xz_;  // abToXZ_b stays in HBM/L2 (147 KB): gathered through the vector L1
-  __device__ __forceinline__ int xz(int i) const { return xz_[i + 8145]; }
   __device__ __forceinline__ int gamma(int i) const { return gamma_.v[i]; }
-  __device__ __forceinline__ int lin(int i) const { return lin_.v[i]; }
-  __device__ __forceinline__ int cbrt(int i) const { return cbrt_.v[i]; }
+  __device__ __forceinline__ float linf(int i) const { return lin_.v[i]; }
+  __device__ __forceinline__ float cbrtf(unsigned i) const { return cbrt_.v[i]; }
   __device__ __forceinline__ unsigned yf(int i) const { return yf_.v[i]; }
   __device__ __forceinline__ int invg(int i) const { return invg_.v[i]; }
   __device__ __forceinline__ int sdiv(int i) const { return sdiv_.v[i]; }
@@ -172,11 +176,10 @@ struct LdsTabs {
     for (int i = threadIdx.x; i < (int)(N * sizeof(T) / 4); i += kBlock) d[i] = s[i];
   }
   __device__ __forceinline__ void load(const DevTables* t) {
-    if (threadIdx.x == 0) xz_ = t->xz_tab;
     if constexpr (kGamma) copy(gamma_.v, t->gamma_lut);
     if constexpr (kVig) {
-      copy(lin_.v, t->lin_tab);
-      copy(cbrt_.v, t->cbrt_tab);
+      for (int i = threadIdx.x; i < 256; i += kBlock) lin_.v[i] = (float)t->lin_tab[i];
+      for (int i = threadIdx.x; i < 3072; i += kBlock) cbrt_.v[i] = (float)t->cbrt_tab[i];
       copy(yf_.v, t->yf_tab);
       copy(invg_.v, t->inv_gamma);
     }
@@ -255,39 +258,48 @@ __device__ __forceinline__ int ab_to_xz(int i) {
 }
 
 // BGR -> 8-bit Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93; RGB2Lab_b /
-// Lab2RGBinteger).  `lin` already folds the gamma LUT when the gamma stage is on.
+// Lab2RGBinteger).  The table `linf` already folds the gamma LUT when the gamma stage is on.
+//
+// The forward half runs on v_fma_f32 (2 cycles per wave64 on gfx950, against 4 for the 24-bit
+// integer multiply-add): every operand is a small integer held exactly in fp32 and every sum stays
+// below 2^23, so the products and sums are exact.  floor(T / 2^n) of an integer T is taken as
+// RN((T + 0.5) / 2^n - 0.5) -- never a tie -- by adding the magic constant 1.5 * 2^23 inside the
+// FMA, which leaves the integer in the low mantissa bits.
 template <typename Tabs>
-__device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs& tb, const int* fwd, const int* inv,
+__device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs& tb, const float* fwd, const int* inv,
                                                float mask, int& b, int& g, int& r) {
-  constexpr int kShift2 = 15;
-  int v0 = tb.lin(b), v1 = tb.lin(g), v2 = tb.lin(r);
-  // nested form -> v_mad_i32_i24 chains (3 instructions per sum)
-  int fX = tb.cbrt((mul24(v2, fwd[2]) + (mul24(v1, fwd[1]) + (mul24(v0, fwd[0]) + 2048))) >> 12);
-  int fY = tb.cbrt((mul24(v2, fwd[5]) + (mul24(v1, fwd[4]) + (mul24(v0, fwd[3]) + 2048))) >> 12);
-  int fZ = tb.cbrt((mul24(v2, fwd[8]) + (mul24(v1, fwd[7]) + (mul24(v0, fwd[6]) + 2048))) >> 12);
-  const int Lscale = (116 * 255 + 50) / 100;
-  const int Lshift = -((16 * 255 * (1 << kShift2) + 50) / 100);
-  int L = (mul24(Lscale, fY) + (Lshift + (1 << 14))) >> kShift2;  // in [0,255] by construction
-  int a = (mul24(500, fX - fY) + (128 * (1 << kShift2) + (1 << 14))) >> kShift2;
-  int bb = (mul24(200, fY - fZ) + (128 * (1 << kShift2) + (1 << 14))) >> kShift2;
+  constexpr float kMagic = 12582912.0f;        // 1.5 * 2^23: ulp 1 in [2^23, 2^24)
+  constexpr unsigned kMagicBits = 0x4B400000u;  // bit pattern of kMagic
+  const float v0 = tb.linf(b), v1 = tb.linf(g), v2 = tb.linf(r);
+  // (C . v + 2048) >> 12 == RN((C . v + 0.5) / 4096): sums <= 2040 * 4096 + 0.5 < 2^23
+  const float sx = __builtin_fmaf(v2, fwd[2], __builtin_fmaf(v1, fwd[1], __builtin_fmaf(v0, fwd[0], 0.5f)));
+  const float sy = __builtin_fmaf(v2, fwd[5], __builtin_fmaf(v1, fwd[4], __builtin_fmaf(v0, fwd[3], 0.5f)));
+  const float sz = __builtin_fmaf(v2, fwd[8], __builtin_fmaf(v1, fwd[7], __builtin_fmaf(v0, fwd[6], 0.5f)));
+  const unsigned ix = __float_as_uint(__builtin_fmaf(sx, 1.0f / 4096.0f, kMagic)) - kMagicBits;
+  const unsigned iy = __float_as_uint(__builtin_fmaf(sy, 1.0f / 4096.0f, kMagic)) - kMagicBits;
+  const unsigned iz = __float_as_uint(__builtin_fmaf(sz, 1.0f / 4096.0f, kMagic)) - kMagicBits;
+  const float fX = tb.cbrtf(ix), fY = tb.cbrtf(iy), fZ = tb.cbrtf(iz);
+  // L = (296 fY - 1336935 + 16384) >> 15, in [0, 255] by construction
+  const float tl = __builtin_fmaf(fY, 296.0f, -1336934.5f);  // T + 0.5 - 16384, T = 296 fY - 1320551 >= 0
+  const float Lf = __builtin_fmaf(tl, 1.0f / 32768.0f, kMagic) - kMagic;
+  const int L = sat_round_u8(Lf * mask);  // convertTo(32F), multiply, convertTo(8U)
+  // a = clamp((500 (fX - fY) + 128 * 2^15 + 2^14) >> 15, 0, 255); outside [0, 2^23) the FMA may round,
+  // but those values clamp to the same end of the range anyway
+  const float ta = __builtin_fmaf(fX - fY, 500.0f, 4194304.5f);
+  const float tb2 = __builtin_fmaf(fY - fZ, 200.0f, 4194304.5f);
+  int a = (int)(__float_as_uint(__builtin_fmaf(ta, 1.0f / 32768.0f, kMagic)) - kMagicBits);
+  int bb = (int)(__float_as_uint(__builtin_fmaf(tb2, 1.0f / 32768.0f, kMagic)) - kMagicBits);
   a = clampi(a, 0, 255);
   bb = clampi(bb, 0, 255);
-  L = sat_round_u8((float)L * mask);
-  unsigned yf = tb.yf(L);
-  int y = (int)(yf & 0xffffu), ify = (int)(yf >> 16);
-  int adiv = ((mul24(a, 5 * 53687) + (1 << 7)) >> 13) - 128 * 16384 / 500;
-  int bdiv = ((mul24(bb, 41943) + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
-  int x, z;
-  if (p.xz_from_table) {
-    x = tb.xz(ify + adiv);
-    z = tb.xz(ify - bdiv);
-  } else {
-    x = ab_to_xz(ify + adiv);
-    z = ab_to_xz(ify - bdiv);
-  }
-  int bo = (mul24(inv[2], z) + (mul24(inv[1], y) + (mul24(inv[0], x) + (1 << 13)))) >> 14;
-  int go = (mul24(inv[5], z) + (mul24(inv[4], y) + (mul24(inv[3], x) + (1 << 13)))) >> 14;
-  int ro = (mul24(inv[8], z) + (mul24(inv[7], y) + (mul24(inv[6], x) + (1 << 13)))) >> 14;
+  const unsigned yf = tb.yf(L);
+  const int y = (int)(yf & 0xffffu), ify = (int)(yf >> 16);
+  const int adiv = ((mul24(a, 5 * 53687) + (1 << 7)) >> 13) - 128 * 16384 / 500;
+  const int bdiv = ((mul24(bb, 41943) + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
+  const int x = ab_to_xz(ify + adiv);
+  const int z = ab_to_xz(ify - bdiv);
+  const int bo = mad24(inv[2], z, mad24(inv[1], y, mad24(inv[0], x, 1 << 13))) >> 14;
+  const int go = mad24(inv[5], z, mad24(inv[4], y, mad24(inv[3], x, 1 << 13))) >> 14;
+  const int ro = mad24(inv[8], z, mad24(inv[7], y, mad24(inv[6], x, 1 << 13))) >> 14;
   b = tb.invg(clampi(bo, 0, 4095));
   g = tb.invg(clampi(go, 0, 4095));
   r = tb.invg(clampi(ro, 0, 4095));
@@ -346,7 +358,7 @@ __device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, 
 
 // The pointwise chain after flip.  BITS >= 0: compile-time stage set; BITS < 0: runtime.
 template <int BITS, int WB, typename Tabs>
-__device__ __forceinline__ void pointwise(const ChainParams& p, const FrameWb& w, const Tabs& tb, const int* fwd,
+__device__ __forceinline__ void pointwise(const ChainParams& p, const FrameWb& w, const Tabs& tb, const float* fwd,
                                           const int* inv, float mask, int& b, int& g, int& r) {
   const int bits = BITS >= 0 ? BITS : p.stage_bits;
   apply_wb(WB >= 0 ? WB : p.wb_mode, w, b, g, r);
@@ -372,6 +384,9 @@ __global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
   GlobalTabs tb{p.tabs};
   FrameWb w;
   if (p.wb_mode != WB_NONE) w = p.wb[frame];
+  float fwdf[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) fwdf[k] = (float)p.tabs->lab_fwd[k];
   uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
   uint8_t* tap = p.tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
       t[1] = (uint8_t)g;
       t[2] = (uint8_t)r;
     }
-    pointwise<-1, -1>(p, w, tb, p.tabs->lab_fwd, p.tabs->lab_inv, (p.stage_bits & ST_VIG) ? vignette_mask(p, yd, xd) : 1.0f, b, g, r);
+    pointwise<-1, -1>(p, w, tb, fwdf, p.tabs->lab_inv, (p.stage_bits & ST_VIG) ? vignette_mask(p, yd, xd) : 1.0f, b, g, r);
     uint8_t* o = dst + (size_t)yd * p.dst_step + (size_t)xd * 3;
     o[0] = (uint8_t)b;
     o[1] = (uint8_t)g;
@@ -559,10 +574,11 @@ struct ItemMap {
 template <int BITS, int WB>
 __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
   __shared__ LdsTabs<BITS> tb;
-  __shared__ int s_fwd[9], s_inv[9];
+  __shared__ float s_fwd[9];
+  __shared__ int s_inv[9];
   tb.load(p.tabs);
   if (threadIdx.x < 9) {
-    s_fwd[threadIdx.x] = p.tabs->lab_fwd[threadIdx.x];
+    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
     s_inv[threadIdx.x] = p.tabs->lab_inv[threadIdx.x];
   }
   __syncthreads();

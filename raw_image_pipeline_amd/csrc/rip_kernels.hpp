@@ -26,7 +26,6 @@ struct DevTables {
   int32_t hdiv[256];
   int32_t lab_fwd[9];
   int32_t lab_inv[9];
-  int32_t xz_tab[36865];        // abToXZ_b, index i + 8145 for i in [-8145, 28719]
   // ccc estimator
   float log_tab[256];
   float exp_neg_tab[256];
@@ -86,7 +85,6 @@ struct ChainParams {
   float vig_inv_max, vig_scale;
   int vig_has_max;
   float hsv_gain[3];  // applied to H, S, V
-  int xz_from_table;  // 1: abToXZ_b gathered from DevTables::xz_tab, 0: evaluated arithmetically
   const DevTables* tabs;
 };
 
