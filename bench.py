@@ -201,10 +201,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = pipe.profile_end()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from raw_image_pipeline_amd import sharding
+    elapsed = sharding.max_over_ranks(elapsed)  # the job is as slow as its slowest rank
 
     total_frames = args.batch * args.steps * world
     fps = total_frames / elapsed

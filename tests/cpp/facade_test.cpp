@@ -1,0 +1,91 @@
+// Exercises include/raw_image_pipeline/raw_image_pipeline.hpp the way a reference caller would
+// (raw_image_pipeline_ros.cpp:36-182 setters, :237 apply(), getters).  Built as C++14 like the reference.
+// usage: facade_test host | facade_test gpu <width> <height> <out.bin>
+#include <raw_image_pipeline/raw_image_pipeline.hpp>
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+using raw_image_pipeline::Mat;
+using raw_image_pipeline::RawImagePipeline;
+
+static int fail(const char* what) {
+  std::printf("FAIL: %s\n", what);
+  return 1;
+}
+
+int main(int argc, char** argv) {
+  const std::string mode = argc > 1 ? argv[1] : "host";
+  RawImagePipeline proc(false, "", "", "");
+  // setters as the ROS wrapper calls them
+  proc.setDebayer(true);
+  proc.setDebayerEncoding("auto");
+  proc.setFlip(true);
+  proc.setFlipAngle(180);
+  proc.setWhiteBalance(true);
+  proc.setWhiteBalanceMethod("gray_world");
+  proc.setWhiteBalancePercentile(10.0);
+  proc.setWhiteBalanceSaturationThreshold(0.8, 0.2);
+  proc.setWhiteBalanceTemporalConsistency(false);
+  proc.setColorCalibration(true);
+  proc.setColorCalibrationMatrix({1.5, -0.25, 0.0, 0.125, 1.0, -0.125, 0.0, -0.5, 1.75});
+  proc.setColorCalibrationBias({1.0, -2.0, 3.5});
+  proc.setGammaCorrection(true);
+  proc.setGammaCorrectionMethod("custom");
+  proc.setGammaCorrectionK(0.8);
+  proc.setVignettingCorrection(true);
+  proc.setVignettingCorrectionParameters(1.5, 1e-3, 1e-6);
+  proc.setColorEnhancer(false);
+  proc.setUndistortion(false);
+  if (!proc.isFlipEnabled() || !proc.isGammaCorrectionEnabled() || proc.isUndistortionEnabled()) return fail("flags");
+  Mat m = proc.getColorCalibrationMatrix();
+  if (m.rows != 3 || m.cols != 3 || m.at<double>(2, 2) != 1.75) return fail("colour matrix getter");
+  if (proc.getDistDistortionModel() != "none") return fail("dist model without calibration");
+  // exceptions: same types as the reference
+  try {
+    proc.setColorCalibrationMatrix({1.0, 2.0});
+    return fail("short matrix accepted");
+  } catch (const std::invalid_argument&) {
+  }
+  if (mode == "host") {
+    try {
+      Mat img(8, 8, 1);
+      std::string enc = "bayer_rggb8";
+      proc.apply(img, enc);
+      return fail("frame processed without a device");
+    } catch (const std::runtime_error& e) {
+      std::printf("expected failure: %s\n", e.what());
+    }
+    std::printf("facade host OK\n");
+    return 0;
+  }
+  const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+  Mat bayer(h, w, 1);
+  unsigned s = 12345u;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      s = s * 1664525u + 1013904223u;  // LCG, reproduced by the Python side of the test
+      bayer.data[(size_t)y * bayer.step + x] = (uint8_t)(s >> 24);
+    }
+  std::string enc = "bayer_rggb8";
+  Mat out = proc.process(bayer, enc);
+  if (enc != "bgr8" || out.rows != h || out.cols != w || out.channels() != 3) return fail("process geometry");
+  std::string enc2 = "bayer_rggb8";
+  Mat inplace = bayer.clone();
+  if (!proc.apply(inplace, enc2) || enc2 != "bgr8" || inplace.channels() != 3) return fail("apply re-seat");
+  if (std::memcmp(inplace.data, out.data, (size_t)w * h * 3) != 0) return fail("apply != process");
+  Mat tap = proc.getDistDebayeredImage(), col = proc.getDistColorImage(), fin = proc.getProcessedImage();
+  if (tap.rows != h || col.rows != h || fin.rows != h || !proc.getRectMask().empty()) return fail("taps");
+  if (std::memcmp(fin.data, out.data, (size_t)w * h * 3) != 0) return fail("processed tap");
+  try {
+    std::string e16 = "bayer_rggb16";
+    proc.process(bayer, e16);
+    return fail("16-bit bayer accepted");
+  } catch (const std::invalid_argument&) {
+  }
+  std::ofstream f(argv[4], std::ios::binary);
+  f.write(reinterpret_cast<const char*>(out.data), (std::streamsize)w * h * 3);
+  std::printf("facade gpu OK\n");
+  return 0;
+}

@@ -1,0 +1,355 @@
+"""Known-answer tests that pin the CPU oracle (PARITY UNPINNED otherwise: the reference has no tests
+or golden vectors and OpenCV is not installed here).  Every expected value below is derived by hand
+from the reference text or from the published OpenCV 4.2 algorithm -- never from running the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from raw_image_pipeline_amd import synth
+
+
+# ---- debayer (debayer.cpp:45-79 -> cv::demosaicing bilinear + RGB2BGR) ---------------------------------
+def hand_debayer(bayer, pattern):
+    """Straight per-pixel transcription of the bilinear rule, independent of the oracle's loop."""
+    cell = synth.PATTERNS[pattern]
+    h, w = bayer.shape
+    s = bayer.astype(np.int32)
+    out = np.zeros((h, w, 3), np.int32)
+    for y in range(1, h - 1):
+        for x in range(1, w - 1):
+            c = cell[y & 1][x & 1]
+            if c == 1:
+                hc = cell[y & 1][(x + 1) & 1]
+                out[y, x, 1] = s[y, x]
+                out[y, x, hc] = (s[y, x - 1] + s[y, x + 1] + 1) >> 1
+                out[y, x, 2 - hc] = (s[y - 1, x] + s[y + 1, x] + 1) >> 1
+            else:
+                out[y, x, c] = s[y, x]
+                out[y, x, 1] = (s[y, x - 1] + s[y, x + 1] + s[y - 1, x] + s[y + 1, x] + 2) >> 2
+                out[y, x, 2 - c] = (s[y - 1, x - 1] + s[y - 1, x + 1] + s[y + 1, x - 1] + s[y + 1, x + 1] + 2) >> 2
+    out[:, 0] = out[:, 1]
+    out[:, -1] = out[:, -2]
+    out[0] = out[1]
+    out[-1] = out[-2]
+    return out.astype(np.uint8)
+
+
+@pytest.mark.parametrize("pattern", sorted(synth.PATTERNS))
+def test_debayer_matches_hand_transcription(oracle, pattern):
+    bayer = np.random.default_rng(1).integers(0, 256, (12, 14), dtype=np.uint8)
+    assert np.array_equal(oracle.debayer(bayer, pattern), hand_debayer(bayer, pattern))
+
+
+def test_debayer_constant_colour_planes(oracle):
+    # a mosaic of a constant colour must demosaic to that colour everywhere (all taps equal)
+    bgr = np.empty((10, 12, 3), np.uint8)
+    bgr[:] = (30, 120, 200)
+    for pattern in synth.PATTERNS:
+        out = oracle.debayer(synth.mosaic(bgr, pattern), pattern)
+        assert (out == np.array([30, 120, 200], np.uint8)).all(), pattern
+
+
+def test_debayer_equals_reference_call_sequence(oracle):
+    # the reference demosaics with the R/B-exchanged OpenCV code and then swaps R and B back
+    # (debayer.cpp:48-52); both routes must agree
+    bayer = np.random.default_rng(2).integers(0, 256, (16, 20), dtype=np.uint8)
+    names = ["bayer_rggb8", "bayer_grbg8", "bayer_gbrg8", "bayer_bggr8"]
+    for i, name in enumerate(names):
+        assert np.array_equal(oracle.debayer(bayer, name), oracle.swap_rb(oracle.debayer(bayer, names[3 - i])))
+
+
+# ---- flip (flip.cpp:37-58) ---------------------------------------------------------------------------------
+def test_flip_permutations(oracle):
+    img = np.arange(4 * 5 * 3, dtype=np.uint8).reshape(4, 5, 3)
+    assert np.array_equal(oracle.flip(img, 180), img[::-1, ::-1])
+    assert np.array_equal(oracle.flip(img, 90), np.rot90(img, k=-1))   # transpose + mirror x = clockwise
+    assert np.array_equal(oracle.flip(img, 270), np.rot90(img, k=1))   # transpose + mirror y = counter-clockwise
+    assert np.array_equal(oracle.flip(img, 0), img)
+    assert np.array_equal(oracle.flip(img, 45), img)                   # any other angle: nothing
+    assert np.array_equal(oracle.flip(oracle.flip(img, 90), 270), img)
+
+
+# ---- gamma (gamma_correction.cpp:35-43) ------------------------------------------------------------------
+def test_gamma_lut_known_entries(oracle):
+    # values computed by restating the five lines of GammaCorrectionModule::init()
+    idx = [1, 2, 16, 64, 128, 200, 254]
+    assert list(oracle.gamma_lut(0.8)[idx]) == [3, 5, 28, 84, 147, 210, 254]
+    assert list(oracle.gamma_lut(0.9)[idx]) == [2, 3, 21, 73, 137, 205, 254]
+    assert np.array_equal(oracle.gamma_lut(1.0), np.arange(256, dtype=np.uint8))
+    lut = oracle.gamma_lut(0.8)
+    assert lut[0] == 0 and lut[255] == 255 and (np.diff(lut.astype(int)) >= 0).all()
+
+
+def test_gamma_lut_literal_formula(oracle):
+    for k in (0.45, 0.8, 2.2):
+        exp = []
+        for i in range(256):
+            f = np.float32(i / 255.0)
+            f = np.float32(math.pow(float(f), k))
+            v = float(f) * 255.0
+            exp.append(min(255, max(0, int(np.rint(v)))))
+        assert list(oracle.gamma_lut(k)) == exp
+
+
+# ---- grey world (xphoto GrayworldWB) -------------------------------------------------------------------------
+def test_grayworld_hand_example(oracle):
+    # two unsaturated pixels and one saturated one that must be skipped
+    img = np.array([[[100, 50, 200], [60, 30, 120], [0, 255, 255]]], np.uint8)
+    # thr 0.9 -> thresh255 = 230 (cvRound(229.5) = 230, half to even);  pixel 3: (255-0)*255 > 230*255 -> skipped
+    out, sums, ig = oracle.wb_grayworld(img, 0.9, return_stats=True)
+    assert sums == [160, 80, 320]
+    # gains = max/sum = (2, 4, 1) / 4 -> Q8 (128, 256, 64)
+    assert ig == [128, 256, 64]
+    assert out.tolist() == [[[50, 50, 50], [30, 30, 30], [0, 255, 63]]]
+
+
+def test_grayworld_uniform_grey_is_identity(oracle):
+    img = np.full((6, 7, 3), 90, np.uint8)
+    assert np.array_equal(oracle.wb_grayworld(img, 0.8), img)
+
+
+# ---- colour matrix (color_calibration.cpp:91-104) -------------------------------------------------------------
+def test_color_matrix_rounding_and_saturation(oracle):
+    img = np.array([[[10, 20, 30], [255, 255, 255], [1, 1, 1]]], np.uint8)
+    m = [1, 0, 0, 0, 0.5, 0, 0.25, 0.25, 0.25]
+    out = oracle.color_matrix(img, m, [0.5, 0.0, -100.0])
+    # B: 10 + .5 = 10.5 -> 10 (half to even); G: 10; R: 15 - 100 -> 0
+    assert out[0, 0].tolist() == [10, 10, 0]
+    # B: 255.5 -> 256 -> 255; G: 127.5 -> 128 (even); R: 191.25 - 100 = 91
+    assert out[0, 1].tolist() == [255, 128, 91]
+    assert out[0, 2].tolist() == [2, 0, 0]  # 1.5 -> 2 (even); 0.5 -> 0 (even)
+    ident = oracle.color_matrix(img, [1, 0, 0, 0, 1, 0, 0, 0, 1], [0, 0, 0])
+    assert np.array_equal(ident, img)
+
+
+# ---- vignetting mask (vignetting_correction.cpp:32-63) --------------------------------------------------------
+def test_vignetting_mask_known_values(oracle):
+    m = oracle.vignetting_mask(2048, 2448, 1.5, 1e-3, 1e-6)
+    assert m.shape == (2048, 2448)
+    assert m[1024, 1224] == np.float32(1.0)      # r = 0
+    assert m[0, 0] == np.float32(2.5)            # the farthest pixel defines the maximum: 1 + scale
+    # mid left edge: r^2 = 1224^2
+    r2 = 1224.0 ** 2
+    rmax2 = 1224.0 ** 2 + 1024.0 ** 2
+    k = lambda s: s * 1e-3 + s * s * 1e-6
+    assert abs(float(m[1024, 0]) - (1 + 1.5 * k(r2) / k(rmax2))) < 1e-6
+    # the double argument swap of the reference cancels: geometry follows (row, col)
+    small = oracle.vignetting_mask(4, 8, 1.0, 1.0, 0.0)
+    assert small[2, 4] == 1.0 and small[0, 0] == 2.0 and small[2, 0] > small[0, 4]
+
+
+def test_vignetting_identity_mask_is_lab_roundtrip(oracle):
+    img = np.random.default_rng(3).integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    ones = np.ones((8, 8), np.float32)
+    assert np.array_equal(oracle.vignetting(img, ones), oracle.lab2bgr(oracle.bgr2lab(img)))
+
+
+# ---- 8-bit Lab / HSV (OpenCV color_lab.cpp / color_hsv.cpp) ---------------------------------------------------
+def test_lab_known_points(oracle):
+    px = np.array([[[0, 0, 0], [255, 255, 255], [128, 128, 128]]], np.uint8)
+    lab = oracle.bgr2lab(px)
+    assert lab[0, 0].tolist() == [0, 128, 128]
+    assert lab[0, 1].tolist() == [255, 128, 128]
+    assert lab[0, 2, 1] == 128 and lab[0, 2, 2] == 128 and abs(int(lab[0, 2, 0]) - 137) <= 1  # L*(0.2159) = 53.6 -> 136.7
+    assert np.array_equal(oracle.lab2bgr(lab)[0, :2], px[0, :2])
+    # pure sRGB red: L* = 53.24, a* = 80.09, b* = 67.20 (textbook values)
+    red = oracle.bgr2lab(np.array([[[0, 0, 255]]], np.uint8))[0, 0]
+    assert abs(int(red[0]) - round(53.24 * 2.55)) <= 1 and abs(int(red[1]) - 208) <= 1 and abs(int(red[2]) - 195) <= 1
+
+
+def test_lab_tables_closed_forms(oracle):
+    g = oracle.table("srgb_gamma")
+    assert g[0] == 0 and g[255] == 2040 and g[10] == round(2040 * (10 / 255) / 12.92)
+    assert abs(int(g[128]) - 2040 * ((128 / 255 + 0.055) / 1.055) ** 2.4) <= 1
+    cb = oracle.table("cbrt")
+    assert cb[0] == round(32768 * 16 / 116) and cb[2040] == 32768
+    yf = oracle.table("lab_to_yf")
+    assert yf[2 * 255] == 16384 and yf[2 * 255 + 1] == 16384 and yf[1] == round(16384 * 16 / 116)
+    assert oracle.table("fwd_coeffs").reshape(3, 3).sum(axis=1).tolist() == [4096, 4096, 4096]
+    # abToXZ_b: linear below 6/29, cube above, continuous at the switch
+    assert oracle.ab_to_xz(16384) == 16384 and oracle.ab_to_xz(0) == -290 and oracle.ab_to_xz(3390) == 145
+    assert oracle.ab_to_xz(3391) == (3391 * 3391 // 16384) * 3391 // 16384
+    assert oracle.ab_to_xz(-8145) == -(8145 * 108 // 841) - 290  # C truncation toward zero
+
+
+def test_hsv_known_points(oracle):
+    px = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0], [255, 255, 255], [0, 0, 0], [50, 100, 200]]], np.uint8)
+    hsv = oracle.bgr2hsv(px)[0]
+    assert hsv[0].tolist() == [0, 255, 255]      # red
+    assert hsv[1].tolist() == [60, 255, 255]     # green: 120 deg / 2
+    assert hsv[2].tolist() == [120, 255, 255]    # blue
+    assert hsv[3].tolist() == [0, 0, 255] and hsv[4].tolist() == [0, 0, 0]
+    # (b,g,r) = (50,100,200): v=200, diff=150, s = 255*150/200 = 191.25 -> 191, h = 60*(g-b)/diff /2 = 10
+    assert hsv[5].tolist() == [10, 191, 200]
+    assert np.array_equal(oracle.hsv2bgr(oracle.bgr2hsv(px[:, :5])), px[:, :5])
+
+
+def test_color_enhancer_identity_gain_is_hsv_roundtrip(oracle):
+    img = np.random.default_rng(4).integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.color_enhance(img, 1.0, 1.0, 1.0), oracle.hsv2bgr(oracle.bgr2hsv(img)))
+    grey = np.full((2, 2, 3), 77, np.uint8)
+    assert np.array_equal(oracle.color_enhance(grey, 1.0, 3.0, 1.0), grey)  # s == 0 stays grey
+
+
+# ---- remap (cv::remap INTER_LINEAR, BORDER_CONSTANT 0) -----------------------------------------------------------
+def test_remap_identity_and_weights(oracle):
+    img = np.random.default_rng(5).integers(0, 256, (6, 7, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:6, 0:7].astype(np.float32)
+    assert np.array_equal(oracle.remap(img, xx, yy), img)
+    # quarter-pixel offsets: weights from the 1/32 grid: fx = 8/32, fy = 16/32
+    mx = np.full((1, 1), 2.25, np.float32)
+    my = np.full((1, 1), 3.5, np.float32)
+    p = img.astype(np.int64)
+    exp = (p[3, 2] * 32 * 24 * 16 + p[3, 3] * 32 * 8 * 16 + p[4, 2] * 32 * 24 * 16 + p[4, 3] * 32 * 8 * 16 + (1 << 14)) >> 15
+    assert oracle.remap(img, mx, my)[0, 0].tolist() == exp.tolist()
+    # coordinates are quantised to 1/32 px with round-half-even: 2 + 1/64 -> 2.0 exactly (tie to even)
+    assert np.array_equal(oracle.remap(img, np.full((1, 1), 2 + 1 / 64, np.float32), np.full((1, 1), 1.0, np.float32))[0, 0], img[1, 2])
+
+
+def test_remap_border_constant(oracle):
+    img = np.full((4, 4, 3), 200, np.uint8)
+    def one(x, y):
+        return oracle.remap(img, np.full((1, 1), x, np.float32), np.full((1, 1), y, np.float32))[0, 0, 0]
+    assert one(-1.0, 1.0) == 0 and one(4.0, 1.0) == 0 and one(1.0, -1.0) == 0 and one(1.0, 4.0) == 0
+    assert one(-0.5, 1.0) == 100          # half of the weight falls on the zero border
+    assert one(3.5, 1.0) == 100 and one(3.0, 3.0) == 200 and one(3.5, 3.5) == 50
+    assert one(float("nan"), 1.0) == 0 and one(1e30, 1.0) == 0
+
+
+# ---- fisheye (cv::fisheye::initUndistortRectifyMap / estimateNewCameraMatrix...) ----------------------------------
+def test_fisheye_maps_closed_form(oracle):
+    K = [100.0, 0, 50.0, 0, 100.0, 40.0, 0, 0, 1]
+    R = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    D = [0.0, 0.0, 0.0, 0.0]
+    mx, my = oracle.fisheye_maps(K, D, R, K, (100, 80))
+    # zero coefficients: theta_d = theta = atan(r): u = f * x * atan(r)/r + c
+    j, i = 80, 10
+    x, y = (j - 50.0) / 100.0, (i - 40.0) / 100.0
+    r = math.hypot(x, y)
+    assert abs(mx[i, j] - (100.0 * x * math.atan(r) / r + 50.0)) < 1e-4
+    assert abs(my[i, j] - (100.0 * y * math.atan(r) / r + 40.0)) < 1e-4
+    assert mx[40, 50] == 50.0 and my[40, 50] == 40.0  # principal point maps to itself
+
+
+def test_fisheye_new_camera_matrix_properties(oracle):
+    cam = synth.camera_model(640, 480)
+    size = (640, 480)
+    k_min = oracle.fisheye_new_camera_matrix(cam["K"], cam["D"], size, cam["R"], 1.0, None, 1.0)
+    k_max = oracle.fisheye_new_camera_matrix(cam["K"], cam["D"], size, cam["R"], 0.0, None, 1.0)
+    assert k_min[0, 0] < k_max[0, 0]                       # balance interpolates between fmin and fmax
+    k_half = oracle.fisheye_new_camera_matrix(cam["K"], cam["D"], size, cam["R"], 0.0, None, 2.0)
+    assert abs(k_half[0, 0] * 2.0 - k_max[0, 0]) < 1e-9    # fov_scale divides the focal length
+    k_resized = oracle.fisheye_new_camera_matrix(cam["K"], cam["D"], size, cam["R"], 0.0, (320, 240), 1.0)
+    assert np.allclose(k_resized[:2], k_max[:2] * 0.5)     # new_size rescales f and c
+    assert k_max[2].tolist() == [0, 0, 1] and k_max[0, 1] == 0 and k_max[1, 0] == 0
+
+
+# ---- ccc (convolutional_color_constancy.cpp) -------------------------------------------------------------------
+def test_ccc_gain_formula(oracle):
+    # gains = exp(k/64 - 1.421875) normalised by the minimum (computeGains :342-381)
+    g = oracle.ccc_gains_from_uv(100, 120)
+    lu, lv = 100 / 64 - 1.421875, 120 / 64 - 1.421875
+    r, gg, b = math.exp(lu), 1.0, math.exp(lv)
+    f = min(r, gg, b)
+    assert np.allclose(g, [b / f, gg / f, r / f], rtol=1e-6)
+    assert oracle.ccc_gains_from_uv(91, 91) == pytest.approx([1.0, 1.0, 1.0], abs=1e-6)  # uv0 = -91/64
+
+
+def test_ccc_fft_response_matches_direct_convolution(oracle):
+    filt, bias = synth.ccc_model()
+    bias = bias + np.random.default_rng(6).normal(0, 1e-5, bias.shape).astype(np.float32)
+    c = oracle.CCC(filt, bias)
+    hist = np.zeros((256, 256), np.float32)
+    hist[40, 200] = 0.5
+    hist[41, 201] = 0.3
+    hist[250, 3] = 0.2
+    resp = c.response(hist) / 65536.0       # unscaled forward and inverse transforms
+    direct = c.response_direct(hist)
+    assert np.abs(resp - direct).max() < 1e-6 * max(1.0, np.abs(direct).max())
+    assert np.unravel_index(resp.argmax(), resp.shape) == np.unravel_index(direct.argmax(), direct.shape)
+
+
+def test_ccc_histogram_binning(oracle):
+    filt, bias = synth.ccc_model()
+    c = oracle.CCC(filt, bias)
+    c.set_thresholds(0.9, 0.1)
+    small = np.zeros((270, 360, 3), np.uint8)
+    small[:] = (50, 100, 200)          # one colour everywhere: a single populated bin
+    h = c.histogram(small)
+    u = int(round((math.log(100) - math.log(200) + 1.421875) * 64))
+    v = int(round((math.log(100) - math.log(50) + 1.421875) * 64))
+    assert np.count_nonzero(h) == 1 and h[u, v] > 0.99     # hist.at(u, v): row u, column v
+    small[:] = (1, 1, 1)               # darker than 255 * dark_thr: masked out
+    assert np.count_nonzero(c.histogram(small)) == 0
+    small[:] = (0, 100, 100)           # log(0) = -inf: skipped
+    assert np.count_nonzero(c.histogram(small)) == 0
+
+
+def test_ccc_kalman_models(oracle):
+    filt, bias = synth.ccc_model()
+    frames = [synth.gen_scene_bgr(180, 135, seed=i, tint=(0.6 + 0.08 * i, 1.0, 0.5)) for i in range(4)]
+    free = oracle.CCC(filt, bias)
+    raw = [free.balance(f)[1][:2] for f in frames]
+    assert len(set(map(tuple, raw))) > 1, "the drifting tint must move the argmax"
+    frozen = oracle.CCC(filt, bias)          # pipeline default: H = 0 (one-argument constructor)
+    frozen.set_temporal_consistency(True)
+    used = [frozen.balance(f)[1][2:] for f in frames]
+    assert all(u == used[0] for u in used) and used[0] == raw[0]
+    filt_kf = oracle.CCC(filt, bias)         # loadModel's filter: H = I, R = 10 I, Q = I, P0 = 0
+    filt_kf.set_temporal_consistency(True)
+    filt_kf.set_kalman_model(1.0, 10.0)
+    x = None
+    p = 0.0
+    for i, f in enumerate(frames):
+        info = filt_kf.balance(f)[1]
+        z = info[:2]
+        if i == 0:
+            x = [float(z[0]), float(z[1])]
+            assert info[2:] == z
+            continue
+        pp = p + 1.0
+        k = pp / (pp + 10.0)
+        x = [x[0] + k * (z[0] - x[0]), x[1] + k * (z[1] - x[1])]
+        p = (1 - k) * pp
+        assert info[2:] == [int(x[0]), int(x[1])]
+
+
+# ---- resize used by ccc (cv::resize INTER_LINEAR, 8U) ------------------------------------------------------------
+def test_resize_area_switch_and_constant(oracle):
+    img = np.random.default_rng(7).integers(0, 256, (540, 720, 3), dtype=np.uint8)
+    small = oracle.resize_linear(img, 270, 360)   # exact 2x: INTER_LINEAR silently becomes INTER_AREA
+    p = img.astype(np.int32)
+    exp = (p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(small, exp.astype(np.uint8))
+    flat = np.full((300, 500, 3), 93, np.uint8)
+    assert (oracle.resize_linear(flat, 270, 360) == 93).all()
+
+
+# ---- whole chain ------------------------------------------------------------------------------------------------
+def test_pipeline_all_stages_off_is_debayer_only(oracle):
+    from helpers import cfg, oracle_run
+    frame = synth.gen_frame(32, 24, "bayer_rggb8", seed=9, kind="uniform")
+    out, enc = oracle_run(oracle, cfg(), frame, "bayer_rggb8")
+    assert enc == "bgr8" and np.array_equal(out, oracle.debayer(frame, "bayer_rggb8"))
+    bgr = np.random.default_rng(1).integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    out, enc = oracle_run(oracle, cfg(), bgr, "bgr8")
+    assert enc == "bgr8" and np.array_equal(out, bgr)
+    out, enc = oracle_run(oracle, cfg(), bgr, "rgb8")
+    assert enc == "rgb8" and np.array_equal(out, bgr[..., ::-1])      # swapped, string kept (debayer.cpp:72-73)
+    with pytest.raises(ValueError):
+        oracle_run(oracle, cfg(), frame, "bayer_bggr16")
+
+
+def test_pipeline_reference_schedule_gives_same_pixels(oracle):
+    from helpers import cfg, oracle_params
+    w, h = 96, 64
+    frame = synth.gen_frame(w, h, "bayer_grbg8", seed=10, kind="scene")
+    c = cfg(flip=True, flip_angle=180, wb=True, wb_method="grey_world", cc=True, gamma=True, vig=True, ce=True, ce_sat=1.2,
+            undistort=True, cam=synth.camera_model(w, h))
+    keep = []
+    prm = oracle_params(oracle, c, keep)
+    a, _ = oracle.pipeline(prm, frame, "bayer_grbg8")
+    prm.reference_schedule = 1
+    b, _ = oracle.pipeline(prm, frame, "bayer_grbg8")
+    assert np.array_equal(a, b)
