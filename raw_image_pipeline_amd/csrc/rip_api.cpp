@@ -127,7 +127,7 @@ struct rip_pipeline {
   DevBuf d_stats, d_wb, d_hist, d_work, d_rowbest, d_argmax, d_mid;
   // compiled remap plan (tiled LDS gather), rebuilt when the maps or the source geometry change
   rip::RemapPlan plan;
-  DevBuf d_plan_words, d_plan_tiles;
+  DevBuf d_plan_words, d_plan_tiles, d_plan_border;
   bool plan_uploaded = false;
   bool use_tiled_remap = true;
   int last_batch_frames = 0;
@@ -148,7 +148,7 @@ struct rip_pipeline {
     for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
     for (DevBuf* b : {&d_tabs, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
                       &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col, &d_plan_words,
-                      &d_plan_tiles})
+                      &d_plan_tiles, &d_plan_border})
       b->release();
   }
 };
@@ -221,6 +221,10 @@ void ensure_plan(rip_pipeline* p, int src_rows, int src_cols) {
                              p->stream));
     HIP_CHECK(hipMemcpyAsync(p->d_plan_tiles.ptr, p->plan.tiles.data(), p->plan.tiles.size() * sizeof(rip::RemapTile),
                              hipMemcpyHostToDevice, p->stream));
+    p->d_plan_border.reserve(std::max<size_t>(4, p->plan.border.size() * sizeof(uint32_t)));
+    if (!p->plan.border.empty())
+      HIP_CHECK(hipMemcpyAsync(p->d_plan_border.ptr, p->plan.border.data(), p->plan.border.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, p->stream));
     HIP_CHECK(hipStreamSynchronize(p->stream));
     p->plan_uploaded = true;
   }
@@ -600,6 +604,8 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
       tp.tiles = p->d_plan_tiles.as<rip::RemapTileDesc>();
       tp.tiles_x = p->plan.tiles_x;
       tp.tiles_y = p->plan.tiles_y;
+      tp.border_list = p->d_plan_border.as<uint32_t>();
+      tp.n_border = (int)p->plan.border.size();
       tp.lds_bytes = (unsigned)p->plan.max_lds_bytes;
       ProfScope ps(p, RIP_KERNEL_REMAP);
       done = rip::launch_remap_tiled(tp, p->stream);

@@ -734,6 +734,17 @@ void compile_remap_plan(RemapPlan& plan, const float* map_xy, int drows, int dco
     }
     for (auto& th : pool) th.join();
   }
+  if (drows <= 65535 && dcols <= 65535) {
+    for (size_t t = 0; t < ntiles; t++) {
+      const int ty = (int)(t / plan.tiles_x), tx = (int)(t % plan.tiles_x);
+      const uint32_t* words = plan.words.data() + t * tile_px;
+      for (int k = 0; k < tile_px; k++)
+        if (words[k] == kRemapBorder) {
+          const int y = ty * kRemapTileH + k / kRemapTileW, x = tx * kRemapTileW + k % kRemapTileW;
+          if (y < drows && x < dcols) plan.border.push_back(((uint32_t)y << 16) | (uint32_t)x);
+        }
+    }
+  }
   for (const RemapTile& tile : plan.tiles) {
     plan.max_rect_w = std::max(plan.max_rect_w, tile.w);
     plan.max_rect_h = std::max(plan.max_rect_h, tile.h);

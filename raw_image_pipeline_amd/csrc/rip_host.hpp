@@ -149,6 +149,7 @@ struct RemapPlan {
   int tiles_x = 0, tiles_y = 0;
   std::vector<uint32_t> words;   // tile-major: tile t occupies words[t*1024 .. t*1024+1023], row-major inside
   std::vector<RemapTile> tiles;
+  std::vector<uint32_t> border;  // (y << 16 | x) of every destination pixel marked kRemapBorder
   int max_rect_w = 0, max_rect_h = 0;
   size_t max_lds_bytes = 0;      // over tiles, for a source pixel size of 3 bytes
   bool valid = false;

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 
 namespace rip {
 namespace {
@@ -589,6 +590,9 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
   // depends only on the position (item split, vignetting mask in FP64, addresses) is computed
   // once per item and reused for every frame of the batch.
   const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
+  // small frames do not fill the chip with one frame's chunks: blockIdx.y splits the batch
+  const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
   const int per_xcd = (chunks_per_frame + 7) / 8;
   const int xcd = blockIdx.x & 7;
   const bool flip180 = p.flip_angle == 180;
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
 #pragma unroll
       for (int k = 0; k < 4; k++) mask[ly][k] = (BITS & ST_VIG) ? vignette_mask(p, yd, xbase + k) : 1.0f;
     }
-    for (int frame = 0; frame < p.n_frames; frame++) {
+    for (int frame = f_begin; frame < f_end; frame++) {
       const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
       uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
       uint8_t* tap = p.tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr;
@@ -1179,8 +1183,32 @@ __device__ __forceinline__ void lds_load6(const uint8_t* lds, unsigned a, uint32
   hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
 }
 
+// Destination pixels whose taps straddle the image border (a few thousand per map) are listed by the
+// plan compiler and patched after the tiled kernel by this per-tap kernel, which keeps the heavy
+// border logic out of the tiled kernel's register budget.
+__global__ __launch_bounds__(kBlock) void remap_border_kernel(RemapTiledParams p) {
+  const RemapParams& b = p.base;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.n_border) return;
+  const uint32_t packed = p.border_list[i];
+  const int yd = (int)(packed >> 16), xd = (int)(packed & 0xffffu);
+  const float2 m = reinterpret_cast<const float2*>(b.map_xy)[__umul24((unsigned)yd, (unsigned)b.dcols) + (unsigned)xd];
+  const int frame = blockIdx.y;
+  const RemapSrc s = remap_src(b, frame);
+  int q[3];
+  remap_pixel<3>(s, m.x, m.y, q);
+  uint8_t* d = b.dst + (size_t)frame * b.dst_frame_stride + (__umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u);
+  d[0] = (uint8_t)q[0];
+  d[1] = (uint8_t)q[1];
+  d[2] = (uint8_t)q[2];
+}
+
+// PRE: staging slots (16-byte chunks) per lane held in registers while the previous frame is gathered;
+// 0 = no software pipeline (one LDS buffer, any rectangle size)
+template <int PRE>
 __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int kPre = PRE > 0 ? PRE : 1;
   const RemapParams& b = p.base;
   const int ntiles = p.tiles_x * p.tiles_y;
   const int per_xcd = (ntiles + 7) / 8;
@@ -1188,6 +1216,11 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
   const int tid = threadIdx.x;
   const int lrow = tid >> 4, lgrp = tid & 15;
   const unsigned step = (unsigned)b.src_step;
+  const int f_per_group = (b.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(b.n_frames, f_begin + f_per_group);
+  if (f_begin >= f_end) return;  // uniform for the workgroup
+  uint8_t* const buf0 = lds;
+  uint8_t* const buf1 = lds + p.lds_bytes;  // second staging buffer (double_buffer only)
   for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
     const int tile = xcd * per_xcd + ti;
     if (tile >= ntiles) break;
@@ -1203,56 +1236,100 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
     const unsigned chunks = pitch >> 4;
     const unsigned total = d.w > 0 ? chunks * (unsigned)d.h : 0u;
     const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
-    for (int f = 0; f < b.n_frames; f++) {
-      const RemapSrc s = remap_src(b, f);
-      // ---- stage the source rectangle -----------------------------------------------------------
-      for (unsigned i = tid; i < total; i += kBlock) {
+    // frame-invariant part of the plan words: LDS address of the top-left tap and the x weights
+    unsigned tap_addr[4], wxb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t w = words[k];
+      const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u;
+      tap_addr[k] = __umul24(rely, pitch) + relx * 3u + ph;
+      wxb[k] = (32u - fx) | (fx << 24);
+    }
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u;
+
+    auto gather_store = [&](const uint8_t* buf, int f) {
+      if (!in_image) return;
+      int q[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t w = words[k];
+        if (w >= kPlanBorder) {
+          q[k][0] = q[k][1] = q[k][2] = 0;  // outside: border constant; border pixels: patched by remap_border_kernel
+          continue;
+        }
+        uint32_t t0, t1, b0, b1;  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
+        lds_load6(buf, tap_addr[k], t0, t1);
+        lds_load6(buf, tap_addr[k] + pitch, b0, b1);
+        const unsigned fy = w >> 27, wy0 = 32u - fy, wy1 = fy;
+        const unsigned wB = wxb[k], wx0 = wB & 0xffu, wx1 = wB >> 24;
+        const unsigned wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
+        const unsigned topB = __builtin_amdgcn_udot4(t0, wB, 0u, false);
+        const unsigned topG = __builtin_amdgcn_udot4(t0, wG0, __builtin_amdgcn_udot4(t1, wx1, 0u, false), false);
+        const unsigned topR = __builtin_amdgcn_udot4(t0, wR0, __builtin_amdgcn_udot4(t1, wR1, 0u, false), false);
+        const unsigned botB = __builtin_amdgcn_udot4(b0, wB, 0u, false);
+        const unsigned botG = __builtin_amdgcn_udot4(b0, wG0, __builtin_amdgcn_udot4(b1, wx1, 0u, false), false);
+        const unsigned botR = __builtin_amdgcn_udot4(b0, wR0, __builtin_amdgcn_udot4(b1, wR1, 0u, false), false);
+        // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15, exact
+        q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1) + 512u) >> 10);
+        q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1) + 512u) >> 10);
+        q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1) + 512u) >> 10);
+      }
+      uint8_t* dst = b.dst + (size_t)f * b.dst_frame_stride;
+      store12(dst + dst_off, pack4(q));
+    };
+
+    if (PRE > 0) {
+      // software pipeline: the global loads of frame f+1 are in flight while frame f is gathered out
+      // of the other LDS buffer; one barrier per frame
+      unsigned goff[kPre], loff[kPre];
+#pragma unroll
+      for (int j = 0; j < kPre; j++) {
+        const unsigned i = (unsigned)tid + (unsigned)j * kBlock;
         int r, c;
         cm.split((int)i, r, c);
-        const unsigned off = __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4);
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (off + 16u <= s.readable) v = *reinterpret_cast<const uint4*>(s.frame + off);
-        *reinterpret_cast<uint4*>(lds + (__umul24((unsigned)r, pitch) + ((unsigned)c << 4))) = v;
+        goff[j] = i < total ? __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFFFu;
+        loff[j] = __umul24((unsigned)r, pitch) + ((unsigned)c << 4);
       }
-      __syncthreads();
-      // ---- gather -----------------------------------------------------------------------------------
-      if (in_image) {
-        int q[4][3];
+      uint4 pre[kPre];
+      auto issue = [&](const RemapSrc& s) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t w = words[k];
-          if (w >= kPlanBorder) {
-            if (w == kPlanBorder) {
-              const float2 m = reinterpret_cast<const float2*>(b.map_xy)[__umul24((unsigned)yd, (unsigned)b.dcols) + (unsigned)(xd + k)];
-              remap_pixel<3>(s, m.x, m.y, q[k]);
-            } else {
-              q[k][0] = q[k][1] = q[k][2] = 0;
-            }
-            continue;
-          }
-          const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu;
-          const unsigned fx = (w >> 22) & 31u, fy = w >> 27;
-          const unsigned a = __umul24(rely, pitch) + relx * 3u + ph;
-          uint32_t t0, t1, b0, b1;  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
-          lds_load6(lds, a, t0, t1);
-          lds_load6(lds, a + pitch, b0, b1);
-          const unsigned wx0 = 32u - fx, wx1 = fx, wy0 = 32u - fy, wy1 = fy;
-          const unsigned wB = wx0 | (wx1 << 24), wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
-          const unsigned topB = __builtin_amdgcn_udot4(t0, wB, 0u, false);
-          const unsigned topG = __builtin_amdgcn_udot4(t0, wG0, __builtin_amdgcn_udot4(t1, wx1, 0u, false), false);
-          const unsigned topR = __builtin_amdgcn_udot4(t0, wR0, __builtin_amdgcn_udot4(t1, wR1, 0u, false), false);
-          const unsigned botB = __builtin_amdgcn_udot4(b0, wB, 0u, false);
-          const unsigned botG = __builtin_amdgcn_udot4(b0, wG0, __builtin_amdgcn_udot4(b1, wx1, 0u, false), false);
-          const unsigned botR = __builtin_amdgcn_udot4(b0, wR0, __builtin_amdgcn_udot4(b1, wR1, 0u, false), false);
-          // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15, exact
-          q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1) + 512u) >> 10);
-          q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1) + 512u) >> 10);
-          q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1) + 512u) >> 10);
+        for (int j = 0; j < kPre; j++) {
+          pre[j] = make_uint4(0u, 0u, 0u, 0u);
+          if (goff[j] != 0xFFFFFFFFu && goff[j] + 16u <= s.readable) pre[j] = *reinterpret_cast<const uint4*>(s.frame + goff[j]);
         }
-        uint8_t* dst = b.dst + (size_t)f * b.dst_frame_stride;
-        store12(dst + (__umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u), pack4(q));
-      }
+      };
+      auto commit = [&](uint8_t* buf) {
+#pragma unroll
+        for (int j = 0; j < kPre; j++)
+          if (goff[j] != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(buf + loff[j]) = pre[j];
+      };
+      issue(remap_src(b, f_begin));
+      commit(buf0);
       __syncthreads();
+      for (int f = f_begin; f < f_end; f++) {
+        uint8_t* cur = ((f - f_begin) & 1) ? buf1 : buf0;
+        uint8_t* nxt = ((f - f_begin) & 1) ? buf0 : buf1;
+        const bool more = f + 1 < f_end;
+        if (more) issue(remap_src(b, f + 1));
+        gather_store(cur, f);
+        if (more) commit(nxt);
+        __syncthreads();
+      }
+    } else {
+      for (int f = f_begin; f < f_end; f++) {
+        const RemapSrc s = remap_src(b, f);
+        for (unsigned i = tid; i < total; i += kBlock) {
+          int r, c;
+          cm.split((int)i, r, c);
+          const unsigned off = __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4);
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (off + 16u <= s.readable) v = *reinterpret_cast<const uint4*>(s.frame + off);
+          *reinterpret_cast<uint4*>(buf0 + (__umul24((unsigned)r, pitch) + ((unsigned)c << 4))) = v;
+        }
+        __syncthreads();
+        gather_store(buf0, f);
+        __syncthreads();
+      }
     }
   }
 }
@@ -1324,7 +1401,8 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     const long long chunks = (long long)((items + kBlock - 1) / kBlock);
     // persistent grid: at most 256 CUs x 8 workgroups, a multiple of 8 (one share per XCD)
     int blocks = (int)std::min<long long>(2048, (chunks + 7) / 8 * 8);
-    dim3 grid(blocks);
+    const int groups = std::max(1, std::min(p.n_frames, 2048 / blocks));
+    dim3 grid(blocks, groups);
     switch (p.stage_bits & 15) {
 #define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream); break;
       RIP_CASE(0) RIP_CASE(1) RIP_CASE(2) RIP_CASE(3) RIP_CASE(4) RIP_CASE(5) RIP_CASE(6) RIP_CASE(7)
@@ -1382,15 +1460,30 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
                   (reinterpret_cast<uintptr_t>(p.words) & 15u) == 0 && b.src_step < (1u << 24) && b.rows < (1 << 23) &&
                   (unsigned long long)b.src_step * (unsigned long long)b.rows < (1ull << 32) && b.dst_step < (1u << 24) &&
                   (unsigned long long)b.dst_step * (unsigned long long)b.drows < (1ull << 32) && p.lds_bytes <= 64u * 1024u &&
-                  p.tiles_x * 64 >= b.dcols && p.tiles_y * 16 >= b.drows;
+                  p.tiles_x * 64 >= b.dcols && p.tiles_y * 16 >= b.drows && b.drows <= 65535 && b.dcols <= 65535;
   if (!ok) return false;
   const int ntiles = p.tiles_x * p.tiles_y;
   // persistent workgroups, a multiple of 8 (one share of the tile range per XCD); LDS bounds residency
-  const unsigned lds = std::max(p.lds_bytes, 16u);
+  RemapTiledParams q = p;
+  q.lds_bytes = (std::max(p.lds_bytes, 16u) + 15u) & ~15u;
+  const unsigned chunks = q.lds_bytes / 16u;  // upper bound of the 16-byte chunks of any tile
+  int pre = b.n_frames < 2 ? 0 : (chunks <= 2u * kBlock ? 2 : (chunks <= 4u * kBlock ? 4 : 0));
+  if (const char* e = std::getenv("RIP_REMAP_PRE")) pre = std::min(pre, std::atoi(e));
+  q.double_buffer = pre > 0 ? 1 : 0;
+  const unsigned lds = q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes;
   const int per_cu = std::max(1, std::min(8, (int)((160u * 1024u) / (lds + 256u))));
   int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
   blocks = std::max(8, blocks / 8 * 8);
-  hipLaunchKernelGGL(remap_tiled_kernel, dim3(blocks), dim3(kBlock), lds, stream, p);
+  const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too
+  const dim3 grid(blocks, groups);
+  if (pre == 2)
+    hipLaunchKernelGGL(remap_tiled_kernel<2>, grid, dim3(kBlock), lds, stream, q);
+  else if (pre == 4)
+    hipLaunchKernelGGL(remap_tiled_kernel<4>, grid, dim3(kBlock), lds, stream, q);
+  else
+    hipLaunchKernelGGL(remap_tiled_kernel<0>, grid, dim3(kBlock), lds, stream, q);
+  if (q.n_border > 0)
+    hipLaunchKernelGGL(remap_border_kernel, dim3((q.n_border + kBlock - 1) / kBlock, b.n_frames), dim3(kBlock), 0, stream, q);
   return true;
 }
 

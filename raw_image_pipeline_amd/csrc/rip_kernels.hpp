@@ -147,7 +147,10 @@ struct RemapTiledParams {
   const uint32_t* words;       // [tiles][1024]
   const RemapTileDesc* tiles;  // [tiles_y * tiles_x]
   int tiles_x, tiles_y;
-  unsigned lds_bytes;          // dynamic LDS per workgroup (>= max over tiles)
+  const uint32_t* border_list; // [n_border] (yd << 16 | xd) of the pixels marked kPlanBorder
+  int n_border;
+  unsigned lds_bytes;          // dynamic LDS per staging buffer (>= max over tiles)
+  int double_buffer;           // set by the launcher: two staging buffers, loads of frame f+1 overlap the gather of f
 };
 
 // ---- launchers (asynchronous on `stream`) -------------------------------------------------------
