@@ -244,18 +244,31 @@ __device__ __forceinline__ float vignette_mask(const ChainParams& p, int row, in
   return m;
 }
 
-// abToXZ_b[i - minABvalue] (OpenCV color_lab.cpp initLabTabs), evaluated arithmetically
-__device__ __forceinline__ int ab_to_xz(int i) {
-  if (i <= 3390) {
-    // i*108/841 (C truncation) - 290, with BASE*16/116*108/841 == 290.  n = i*108 is in
-    // [-879660, 366120]; trunc(n/841) = floor((n + (n<0 ? 840 : 0)) / 841); the floor division is
-    // one v_mul_hi_u32_u24 by ceil(2^32/841) after biasing by 841*1100 (exact below 11.9e6).
-    int n = mul24(i, 108);
-    n += (n >> 31) & 840;
-    unsigned q = umulhi24((unsigned)(n + 841 * 1100), 5106977u);
-    return (int)q - (1100 + 290);
-  }
+// abToXZ_b[i - minABvalue] (OpenCV color_lab.cpp initLabTabs), evaluated arithmetically.
+// i > 3390: the cube i*i/BASE*i/BASE;  i <= 3390 (L* below ~8, dark pixels only): the linear segment
+// i*108/841 - 290 with C truncation.
+__device__ __forceinline__ int ab_to_xz_cube(int i) {
   return mul24(mul24(i, i) >> 14, i) >> 14;  // i in (3390, 28719]: both products < 2^31
+}
+__device__ __forceinline__ int ab_to_xz_linear(int i) {
+  // n = i*108 is in [-879660, 366120]; trunc(n/841) = floor((n + (n<0 ? 840 : 0)) / 841); the floor
+  // division is one v_mul_hi_u32_u24 by ceil(2^32/841) after biasing by 841*1100 (exact below 11.9e6);
+  // BASE*16/116*108/841 == 290
+  int n = mul24(i, 108);
+  n += (n >> 31) & 840;
+  const unsigned q = umulhi24((unsigned)(n + 841 * 1100), 5106977u);
+  return (int)q - (1100 + 290);
+}
+// Both lookups of one pixel.  The linear segment is rare, so it sits behind a wave-uniform branch:
+// hipcc otherwise predicates both sides and issues all of it for every pixel.
+__device__ __forceinline__ void ab_to_xz_pair(int ix, int iz, int& x, int& z) {
+  x = ab_to_xz_cube(ix);
+  z = ab_to_xz_cube(iz);
+  const bool dark = ix <= 3390 || iz <= 3390;
+  if (__builtin_amdgcn_ballot_w64(dark) != 0ull) {
+    if (ix <= 3390) x = ab_to_xz_linear(ix);
+    if (iz <= 3390) z = ab_to_xz_linear(iz);
+  }
 }
 
 // BGR -> 8-bit Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93; RGB2Lab_b /
@@ -296,8 +309,8 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
   const int y = (int)(yf & 0xffffu), ify = (int)(yf >> 16);
   const int adiv = ((mul24(a, 5 * 53687) + (1 << 7)) >> 13) - 128 * 16384 / 500;
   const int bdiv = ((mul24(bb, 41943) + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
-  const int x = ab_to_xz(ify + adiv);
-  const int z = ab_to_xz(ify - bdiv);
+  int x, z;
+  ab_to_xz_pair(ify + adiv, ify - bdiv, x, z);
   const int bo = mad24(inv[2], z, mad24(inv[1], y, mad24(inv[0], x, 1 << 13))) >> 14;
   const int go = mad24(inv[5], z, mad24(inv[4], y, mad24(inv[3], x, 1 << 13))) >> 14;
   const int ro = mad24(inv[8], z, mad24(inv[7], y, mad24(inv[6], x, 1 << 13))) >> 14;
