@@ -669,6 +669,94 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
 }
 
 // ------------------------------------------------------------------------------------------------
+// colour-input path (bgr8 / rgb8 frames, e.g. the reference's Python demo): 4 px per lane, 12-byte
+// loads and stores, flip 0/180, stage set decided at run time (wave-uniform branches), all tables in LDS
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack12(const uint3& v, bool rgb, int (&q)[4][3]) {
+  const uint32_t w[3] = {v.x, v.y, v.z};
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int byte = k * 3 + c;
+      q[k][c] = (int)((w[byte >> 2] >> (8 * (byte & 3))) & 0xFFu);
+    }
+  if (rgb) {  // cvtColor(RGB2BGR), debayer.cpp:72-73
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int t = q[k][0];
+      q[k][0] = q[k][2];
+      q[k][2] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, ItemMap im, int items_per_frame) {
+  __shared__ LdsTabs<ST_CC | ST_GAMMA | ST_VIG | ST_HSV> tb;
+  __shared__ uint8_t s_gamma[256];  // LdsTabs<...VIG> folds gamma into lin_tab; the plain LUT is needed too
+  __shared__ float s_fwd[9];
+  __shared__ int s_inv[9];
+  tb.load(p.tabs);
+  s_gamma[threadIdx.x] = p.tabs->gamma_lut[threadIdx.x];
+  if (threadIdx.x < 9) {
+    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
+    s_inv[threadIdx.x] = p.tabs->lab_inv[threadIdx.x];
+  }
+  __syncthreads();
+  const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
+  const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
+  const bool flip180 = p.flip_angle == 180;
+  const bool rgb = p.src_kind == SRC_RGB;
+  const bool vig = (p.stage_bits & ST_VIG) != 0, gam = (p.stage_bits & ST_GAMMA) != 0;
+  for (int chunk = blockIdx.x; chunk < chunks_per_frame; chunk += gridDim.x) {
+    const int item = chunk * kBlock + threadIdx.x;
+    if (item >= items_per_frame) continue;
+    int ys, grp;
+    im.split(item, ys, grp);
+    const int x0 = grp * 4;
+    const int yd = flip180 ? p.rows - 1 - ys : ys;
+    const int xbase = flip180 ? p.cols - 4 - x0 : x0;
+    float mask[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) mask[k] = vig ? vignette_mask(p, yd, xbase + k) : 1.0f;
+    const unsigned src_off = __umul24((unsigned)ys, (unsigned)p.src_step) + (unsigned)x0 * 3u;
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u;
+    const unsigned tap_off = (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u;
+    for (int frame = f_begin; frame < f_end; frame++) {
+      const uint3 in = *reinterpret_cast<const uint3*>(p.src + (size_t)frame * p.src_frame_stride + src_off);
+      FrameWb w;
+      if (p.wb_mode != WB_NONE) w = p.wb[frame];
+      int s[4][3], q[4][3];
+      unpack12(in, rgb, s);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) q[k][c] = flip180 ? s[3 - k][c] : s[k][c];
+      if (p.tap) store12(p.tap + (size_t)frame * p.tap_frame_stride + tap_off, pack4(q));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int b = q[k][0], g = q[k][1], r = q[k][2];
+        apply_wb(p.wb_mode, w, b, g, r);
+        if (p.stage_bits & ST_CC) apply_cc(p, b, g, r);
+        if (vig) {
+          apply_vignette(p, tb, s_fwd, s_inv, mask[k], b, g, r);
+        } else if (gam) {
+          b = s_gamma[b];
+          g = s_gamma[g];
+          r = s_gamma[r];
+        }
+        if (p.stage_bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+        q[k][0] = b;
+        q[k][1] = g;
+        q[k][2] = r;
+      }
+      store12(p.dst + (size_t)frame * p.dst_frame_stride + dst_off, pack4(q));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // statistics kernels (grey-world sums, pca sums/maxima): integer reductions, wave64 shuffles
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
@@ -750,6 +838,24 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, ItemM
       for (int lx = 0; lx < 4; lx++)
         stat_add(p, (int)((rowpx[ly].b >> (8 * lx)) & 0xFFu), (int)((rowpx[ly].g >> (8 * lx)) & 0xFFu),
                  (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a);
+  }
+  stat_flush(p, a, p.stats + frame);
+}
+
+// colour input (bgr8 / rgb8), 4 px per lane
+__global__ __launch_bounds__(kBlock) void stats_color_kernel(StatsParams p, ItemMap im, int items_per_frame) {
+  const int frame = blockIdx.y;
+  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  const bool rgb = p.src_kind == SRC_RGB;
+  StatAcc a = {};
+  for (int item = blockIdx.x * kBlock + threadIdx.x; item < items_per_frame; item += gridDim.x * kBlock) {
+    int y, grp;
+    im.split(item, y, grp);
+    const uint3 in = *reinterpret_cast<const uint3*>(src + (__umul24((unsigned)y, (unsigned)p.src_step) + (unsigned)grp * 12u));
+    int q[4][3];
+    unpack12(in, rgb, q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) stat_add(p, q[k][0], q[k][1], q[k][2], a);
   }
   stat_flush(p, a, p.stats + frame);
 }
@@ -1399,6 +1505,18 @@ void launch_fast_wb(const ChainParams& p, const ItemMap& im, int items, dim3 gri
 
 }  // namespace
 
+bool color_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, int rows, int cols, int kind) {
+  return (kind == SRC_BGR || kind == SRC_RGB) && cols % 4 == 0 && step % 4 == 0 && frame_stride % 4 == 0 && aligned4(src) &&
+         step < (1u << 24) && rows < (1 << 23) && (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
+}
+
+bool chain_uses_color_path(const ChainParams& p) {
+  return color_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
+         (p.flip_angle == 0 || p.flip_angle == 180) && p.channels == 3 && p.dst_step % 4 == 0 && p.dst_step < (1u << 24) &&
+         (unsigned long long)p.dst_step * (unsigned long long)p.drows < (1ull << 32) && p.dst_frame_stride % 4 == 0 &&
+         aligned4(p.dst) && (!p.tap || (aligned4(p.tap) && p.tap_frame_stride % 4 == 0));
+}
+
 int chain_uses_fast_path(const ChainParams& p) {
   return bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
          (p.flip_angle == 0 || p.flip_angle == 180) && p.channels == 3 && p.dst_step % 4 == 0 &&
@@ -1424,6 +1542,15 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     }
     return;
   }
+  if (chain_uses_color_path(p)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = p.rows * (p.cols / 4);
+    const int chunks = (items + kBlock - 1) / kBlock;
+    const int blocks = std::min(2048, chunks);
+    const int groups = std::max(1, std::min(p.n_frames, 2048 / blocks));
+    hipLaunchKernelGGL(chain_color_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, im, items);
+    return;
+  }
   long long npix = (long long)p.drows * p.dcols;
   dim3 grid(grid_blocks_for(npix, 2048), p.n_frames);
   hipLaunchKernelGGL(chain_generic_kernel, grid, dim3(kBlock), 0, stream, p);
@@ -1438,6 +1565,14 @@ void launch_stats(const StatsParams& p, hipStream_t stream) {
     int per_frame = grid_blocks_for(items, std::max(8, 2048 / std::max(1, std::min(p.n_frames, 16))));
     per_frame = std::max(per_frame, (int)((items + (1 << 20) - 1) >> 20));
     hipLaunchKernelGGL(stats_fast_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
+    return;
+  }
+  if (color_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = p.rows * (p.cols / 4);
+    int per_frame = grid_blocks_for(items, std::max(8, 2048 / std::max(1, std::min(p.n_frames, 16))));
+    per_frame = std::max(per_frame, (int)((items + (1 << 20) - 1) >> 20));
+    hipLaunchKernelGGL(stats_color_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
     return;
   }
   long long npix = (long long)p.rows * p.cols;

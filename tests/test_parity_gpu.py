@@ -179,6 +179,20 @@ def test_full_chain_with_enhancer_and_taps(gpu_pipe, oracle):
     assert gpu_pipe.get_rect_mask().size == 0
 
 
+@pytest.mark.parametrize("encoding", ["bgr8", "rgb8"])
+@pytest.mark.parametrize("wb", ["grey_world", "pca"])
+@pytest.mark.parametrize("size", [(160, 120), (150, 111)])  # vectorised colour path / generic path
+def test_full_chain_on_colour_input(gpu_pipe, oracle, encoding, wb, size):
+    """The reference's Python demo feeds bgr8 images (apply_pipeline.py:49-53)."""
+    w, h = size
+    img = synth.gen_scene_bgr(w, h, seed=31)
+    cam = synth.camera_model(w, h)
+    c = full_chain_cfg(w, h, wb_method=wb, ce=True, ce_sat=1.3, cam=cam)
+    run_both(gpu_pipe, oracle, c, img, encoding, 0, what="colour input %s %s %s" % (encoding, wb, size))
+    c2 = full_chain_cfg(w, h, wb_method=wb, flip=False, undistort=False, vig=False)
+    run_both(gpu_pipe, oracle, c2, img, encoding, 0, what="colour input no-vignette %s %s %s" % (encoding, wb, size))
+
+
 def test_full_chain_full_size_2448x2048(gpu_pipe, oracle):
     """BASELINE configs[1] at its real size, against the oracle (a few seconds of CPU)."""
     w, h = 2448, 2048
