@@ -1,0 +1,222 @@
+"""Streaming front-end: the counterpart of the reference's ROS node (raw_image_pipeline_ros/src/
+raw_image_pipeline_ros.cpp) without ROS -- per-camera parameter set with the node's names and defaults,
+the image callback with its three output taps (``<type>_rect``, ``debayered``, ``<type>``) plus
+CameraInfo, slow-topic decimation, the ``reset_white_balance`` control, output encoding BGR/RGB/
+passthrough -- and a multi-camera rig that shards cameras over the GPUs of a node (camera c -> GPU
+c mod N).  Transport (subscribing / publishing) is the caller's business: the callback
+returns the messages it would have published.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .pipeline import RawImagePipeline
+
+# readParameter defaults of RawImagePipelineRos::loadParams (raw_image_pipeline_ros.cpp:36-182)
+NODE_DEFAULTS = OrderedDict([
+    ("input_type", "color"), ("output_prefix", "/camera"), ("transport", "raw"),
+    ("output_encoding", "BGR"), ("output_frame", "passthrough"), ("skip_number_of_images_for_slow_topic", -1),
+    ("use_gpu", True), ("debug", False),
+    ("debayer/enabled", True), ("debayer/encoding", "auto"),
+    ("flip/enabled", False), ("flip/angle", 0),
+    ("white_balance/enabled", False), ("white_balance/method", "simple"), ("white_balance/clipping_percentile", 10.0),
+    ("white_balance/saturation_bright_thr", 0.9), ("white_balance/saturation_dark_thr", 0.1),
+    ("white_balance/temporal_consistency", False),
+    ("color_calibration/enabled", False), ("color_calibration/calibration_file", ""),
+    ("color_calibration/calibration_matrix/data", [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]),
+    ("color_calibration/calibration_bias/data", [0.0, 0.0, 0.0]),
+    ("gamma_correction/enabled", False), ("gamma_correction/method", "default"), ("gamma_correction/k", 0.8),
+    ("vignetting_correction/enabled", False), ("vignetting_correction/scale", 1.0), ("vignetting_correction/a2", 1.0),
+    ("vignetting_correction/a4", 1.0),
+    ("color_enhancer/enabled", False), ("color_enhancer/hue_gain", 1.0), ("color_enhancer/saturation_gain", 1.0),
+    ("color_enhancer/value_gain", 1.0),
+    ("undistortion/enabled", False), ("undistortion/balance", 0.0), ("undistortion/fov_scale", 1.0),
+    ("undistortion/calibration_file", ""), ("undistortion/image_width", 640), ("undistortion/image_height", 480),
+    ("undistortion/camera_matrix/data", [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]),
+    ("undistortion/distortion_coefficients/data", [0.0, 0.0, 0.0, 0.0]), ("undistortion/distortion_model", "none"),
+    ("undistortion/rectification_matrix/data", [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]),
+    ("undistortion/projection_matrix/data", [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0]),
+])
+
+
+def transport_hint_from_topic(topic):
+    """getTransportHintFromTopic (:349-362): ".../image/compressed" -> (".../image", "compressed")."""
+    ind = topic.find("compressed")
+    if ind != -1:
+        return topic[:ind - 1], topic[ind:]
+    return topic, "raw"
+
+
+class CameraStream:
+    """One camera = one pipeline handle = one HIP stream (RawImagePipelineRos, one node per camera)."""
+
+    def __init__(self, params=None, device=0, ccc_model=None, pipeline=None):
+        unknown = set(params or ()) - set(NODE_DEFAULTS)
+        if unknown:
+            raise KeyError("unknown parameter(s): %s" % sorted(unknown))
+        self.params = OrderedDict(NODE_DEFAULTS)
+        self.params.update(params or {})
+        p = self.params
+        self.input_type = p["input_type"]
+        self.output_prefix = p["output_prefix"]
+        self.transport = p["transport"]
+        self.output_encoding = p["output_encoding"]
+        self.output_frame = p["output_frame"]
+        self.skip = int(p["skip_number_of_images_for_slow_topic"])
+        self._skipped = 0       # skipped_images_for_slow_topic_
+        self._skipped_rect = 0  # skipped_images_for_slow_topic_rect_
+        # raw_image_pipeline_ = std::make_unique<RawImagePipeline>(use_gpu)  (:52): the one-argument constructor
+        self.pipe = pipeline if pipeline is not None else RawImagePipeline(bool(p["use_gpu"]), device=device)
+        self._configure()
+        if ccc_model is not None:
+            self.pipe.set_ccc_model(*ccc_model)
+
+    def _configure(self):
+        p, pipe = self.params, self.pipe
+        pipe.set_debug(p["debug"])
+        pipe.set_debayer(p["debayer/enabled"])
+        pipe.set_debayer_encoding(p["debayer/encoding"])
+        pipe.set_flip(p["flip/enabled"])
+        pipe.set_flip_angle(p["flip/angle"])
+        pipe.set_white_balance(p["white_balance/enabled"])
+        pipe.set_white_balance_method(p["white_balance/method"])
+        pipe.set_white_balance_percentile(p["white_balance/clipping_percentile"])
+        pipe.set_white_balance_saturation_threshold(p["white_balance/saturation_bright_thr"], p["white_balance/saturation_dark_thr"])
+        pipe.set_white_balance_temporal_consistency(p["white_balance/temporal_consistency"])
+        pipe.set_color_calibration(p["color_calibration/enabled"])
+        if p["color_calibration/enabled"]:
+            pipe.load_color_calibration(p["color_calibration/calibration_file"])
+            if not p["color_calibration/calibration_file"]:
+                pipe.set_color_calibration_matrix(p["color_calibration/calibration_matrix/data"])
+                pipe.set_color_calibration_bias(p["color_calibration/calibration_bias/data"])
+        pipe.set_gamma_correction(p["gamma_correction/enabled"])
+        pipe.set_gamma_correction_method(p["gamma_correction/method"])
+        pipe.set_gamma_correction_k(p["gamma_correction/k"])
+        pipe.set_vignetting_correction(p["vignetting_correction/enabled"])
+        pipe.set_vignetting_correction_parameters(p["vignetting_correction/scale"], p["vignetting_correction/a2"],
+                                                  p["vignetting_correction/a4"])
+        pipe.set_color_enhancer(p["color_enhancer/enabled"])
+        pipe.set_color_enhancer_hue_gain(p["color_enhancer/hue_gain"])
+        pipe.set_color_enhancer_saturation_gain(p["color_enhancer/saturation_gain"])
+        pipe.set_color_enhancer_value_gain(p["color_enhancer/value_gain"])
+        pipe.set_undistortion(p["undistortion/enabled"])
+        pipe.set_undistortion_balance(p["undistortion/balance"])
+        pipe.set_undistortion_fov_scale(p["undistortion/fov_scale"])
+        pipe.load_camera_calibration(p["undistortion/calibration_file"])
+        if not p["undistortion/calibration_file"]:
+            # the node reads image_height from the image_width parameter (:156-157); not reproduced
+            pipe.set_undistortion_image_size(p["undistortion/image_width"], p["undistortion/image_height"])
+            pipe.set_undistortion_camera_matrix(p["undistortion/camera_matrix/data"])
+            pipe.set_undistortion_distortion_coeffs(p["undistortion/distortion_coefficients/data"])
+            pipe.set_undistortion_distortion_model(p["undistortion/distortion_model"])
+            pipe.set_undistortion_rectification_matrix(p["undistortion/rectification_matrix/data"])
+            pipe.set_undistortion_projection_matrix(p["undistortion/projection_matrix/data"])
+            pipe.init_undistortion()
+
+    # ---- topics (setupRos :184-217) ------------------------------------------------------------------
+    def topics(self):
+        t = []
+        if self.pipe.is_undistortion_enabled():
+            t += [self.output_prefix + "/" + self.input_type + "_rect/image", self.output_prefix + "/" + self.input_type + "_rect/image/slow"]
+        if self.input_type == "color":
+            t += [self.output_prefix + "/debayered/image", self.output_prefix + "/debayered/slow"]
+        t += [self.output_prefix + "/" + self.input_type + "/image", self.output_prefix + "/" + self.input_type + "/image/slow"]
+        return t
+
+    def reset_white_balance(self):
+        """~reset_white_balance service (:290-295)."""
+        self.pipe.reset_white_balance_temporal_consistency()
+        return True, "White balance resetted"
+
+    # ---- the image callback (:219-288) -------------------------------------------------------------------
+    def on_image(self, image, encoding, stamp=0.0, frame_id="camera"):
+        """Processes one frame and returns the messages the node would publish, in publishing order:
+        a list of dicts {topic, image, encoding, camera_info | None}."""
+        img = np.asarray(image)
+        if img.size == 0:
+            return []  # ROS_WARN("image empty")
+        if self.transport != "raw":
+            encoding = "bgr8"  # cv_bridge::toCvCopy(image_msg, "bgr8") for compressed transports
+        processed = self.pipe.apply(img.copy(), encoding)
+        enc = self.pipe.last_encoding
+        out = []
+        pipe = self.pipe
+        if pipe.is_undistortion_enabled():
+            self._publish(out, processed, enc, stamp, frame_id, self.input_type + "_rect/image", self.input_type + "_rect/image/slow",
+                          pipe.get_rect_image_height(), pipe.get_rect_image_width(), pipe.get_rect_distortion_model(),
+                          pipe.get_rect_distortion_coefficients(), pipe.get_rect_camera_matrix(),
+                          pipe.get_rect_rectification_matrix(), pipe.get_rect_projection_matrix(), "_skipped_rect")
+        dist = (pipe.get_dist_image_height(), pipe.get_dist_image_width(), pipe.get_dist_distortion_model(),
+                pipe.get_dist_distortion_coefficients(), pipe.get_dist_camera_matrix(), pipe.get_dist_rectification_matrix(),
+                pipe.get_dist_projection_matrix())
+        if self.input_type == "color" and pipe.is_debayer_enabled():
+            self._publish(out, pipe.get_dist_debayered_image(), enc, stamp, frame_id, "debayered/image", "debayered/slow", *dist,
+                          "_skipped")
+        color = pipe.get_dist_color_image() if pipe.is_undistortion_enabled() else pipe.get_processed_image()
+        self._publish(out, color, enc, stamp, frame_id, self.input_type + "/image", self.input_type + "/image/slow", *dist, "_skipped")
+        return out
+
+    def _publish(self, out, image, encoding, stamp, frame_id, topic, slow_topic, height, width, model, D, K, R, P, counter):
+        """publishColorImage (:297-347)."""
+        if self.output_encoding == "RGB" and image.ndim == 3:
+            image = image[..., ::-1].copy()  # cv::cvtColor(BGR2RGB)
+        if image.ndim == 3 and image.shape[2] == 3:
+            if self.output_encoding == "RGB":
+                encoding = "rgb8"
+            elif self.output_encoding == "BGR":
+                encoding = "bgr8"
+            elif self.output_encoding != "passthrough":
+                raise ValueError("Found invalid image encoding: %s, make sure to set a supported ouput encoding "
+                                 "('RGB', 'BGR', or 'passthrough')" % self.output_encoding)
+        fid = frame_id if self.output_frame == "passthrough" else self.output_frame
+        info = {"header": {"stamp": stamp, "frame_id": fid}, "height": int(height), "width": int(width),
+                "distortion_model": model, "D": [float(v) for v in np.asarray(D).ravel()],
+                "K": [float(v) for v in np.asarray(K).ravel()], "R": [float(v) for v in np.asarray(R).ravel()],
+                "P": [float(v) for v in np.asarray(P).ravel()]}
+        msg = {"topic": self.output_prefix + "/" + topic, "image": image, "encoding": encoding, "camera_info": info,
+               "header": {"stamp": stamp, "frame_id": fid}}
+        out.append(msg)
+        skipped = getattr(self, counter)
+        if skipped >= self.skip or self.skip <= 0:
+            out.append({"topic": self.output_prefix + "/" + slow_topic, "image": image, "encoding": encoding, "camera_info": None,
+                        "header": {"stamp": stamp, "frame_id": fid}})
+            setattr(self, counter, 0)
+        else:
+            setattr(self, counter, skipped + 1)
+
+
+class CameraRig:
+    """N cameras sharded over the visible GPUs: camera c is owned by device c mod n_devices, keeps its own
+    handle (maps, LUTs, Kalman state resident on that device) and its own HIP stream."""
+
+    def __init__(self, camera_params, n_devices=None, ccc_model=None):
+        import torch
+        n_devices = n_devices or max(1, torch.cuda.device_count())
+        self.streams = []
+        self.devices = []
+        self.hip_streams = []
+        for c, params in enumerate(camera_params):
+            dev = c % n_devices
+            with torch.cuda.device(dev):
+                s = torch.cuda.Stream(device=dev)
+            cam = CameraStream(params, device=dev, ccc_model=ccc_model)
+            cam.pipe.set_stream(s)
+            self.streams.append(cam)
+            self.devices.append(dev)
+            self.hip_streams.append(s)
+
+    def on_images(self, images, encodings, stamp=0.0):
+        """One frame per camera (the synchronised trigger of a multi-camera rig)."""
+        return [cam.on_image(img, enc, stamp=stamp, frame_id="cam%d" % c)
+                for c, (cam, img, enc) in enumerate(zip(self.streams, images, encodings))]
+
+    def process_resident(self, batches, encodings, outs=None):
+        """Device-resident batches, one per camera, each on its owner's device and stream; asynchronous."""
+        res = []
+        for c, (cam, frames, enc) in enumerate(zip(self.streams, batches, encodings)):
+            res.append(cam.pipe.apply_device(frames, enc, out=None if outs is None else outs[c]))
+        return res
+
+    def synchronize(self):
+        for s in self.hip_streams:
+            s.synchronize()

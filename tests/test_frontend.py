@@ -1,0 +1,89 @@
+"""Streaming front-end (counterpart of raw_image_pipeline_ros): parameter mapping on the CPU, topics /
+decimation / camera info / output encoding on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from raw_image_pipeline_amd import RawImagePipeline, synth
+from raw_image_pipeline_amd.frontend import NODE_DEFAULTS, CameraStream, transport_hint_from_topic
+
+CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "configs")
+
+
+def test_transport_hint():
+    assert transport_hint_from_topic("/cam0/image_raw") == ("/cam0/image_raw", "raw")
+    assert transport_hint_from_topic("/cam0/image_raw/compressed") == ("/cam0/image_raw", "compressed")
+
+
+def test_node_defaults_differ_from_yaml_defaults(rip_lib):
+    # the node's defaults are not the YAML loader's
+    assert NODE_DEFAULTS["white_balance/method"] == "simple" and NODE_DEFAULTS["gamma_correction/method"] == "default"
+    assert NODE_DEFAULTS["vignetting_correction/a2"] == 1.0 and NODE_DEFAULTS["white_balance/saturation_bright_thr"] == 0.9
+    cam = CameraStream({}, pipeline=RawImagePipeline(False, device=-1))
+    p = cam.pipe
+    assert p.is_debayer_enabled() and not p.is_white_balance_enabled() and not p.is_undistortion_enabled()
+    # inline calibration without a file: loadCameraCalibration("") marks the calibration unavailable
+    assert p.get_dist_distortion_model() == "none"
+    assert (p.get_dist_image_width(), p.get_dist_image_height()) == (640, 480)
+    assert cam.topics() == ["/camera/debayered/image", "/camera/debayered/slow", "/camera/color/image", "/camera/color/image/slow"]
+    with pytest.raises(KeyError):
+        CameraStream({"white_balance/metod": "ccc"}, pipeline=RawImagePipeline(False, device=-1))
+
+
+def test_parameter_mapping_with_files(rip_lib):
+    cam = CameraStream({"input_type": "mono", "output_prefix": "/alphasense/cam3",
+                        "undistortion/enabled": True, "undistortion/calibration_file": os.path.join(CFG, "calib_64x48.yaml"),
+                        "undistortion/balance": 0.5, "undistortion/fov_scale": 1.2,
+                        "color_calibration/enabled": True, "color_calibration/calibration_file": os.path.join(CFG, "color_calib.yaml"),
+                        "flip/enabled": True, "flip/angle": 180}, pipeline=RawImagePipeline(False, device=-1))
+    p = cam.pipe
+    assert p.is_undistortion_enabled() and p.get_dist_distortion_model() == "equidistant"
+    assert p.get_color_calibration_matrix()[0, 0] == 1.5
+    assert cam.topics()[0] == "/alphasense/cam3/mono_rect/image" and "/alphasense/cam3/debayered/image" not in cam.topics()
+
+
+@pytest.mark.gpu
+def test_callback_topics_decimation_and_camera_info(rip_lib, oracle):
+    from helpers import cfg, oracle_run
+    w, h = 64, 48
+    params = {"output_prefix": "/cam0", "output_encoding": "RGB", "output_frame": "cam0_optical", "skip_number_of_images_for_slow_topic": 2,
+              "flip/enabled": True, "flip/angle": 180, "gamma_correction/enabled": True, "gamma_correction/k": 0.9,
+              "undistortion/enabled": True, "undistortion/calibration_file": os.path.join(CFG, "calib_64x48.yaml")}
+    cam = CameraStream(params, device=0)
+    c = cfg(flip=True, flip_angle=180, gamma=True, gamma_k=0.9, undistort=True, cam=synth.camera_model(w, h))
+    slow_counts = {}
+    for i in range(6):
+        frame = synth.gen_frame(w, h, "bayer_rggb8", seed=50 + i, kind="scene")
+        msgs = cam.on_image(frame, "bayer_rggb8", stamp=1.5 + i, frame_id="ignored")
+        by_topic = {m["topic"]: m for m in msgs}
+        ref, _, t_deb, t_col = oracle_run(oracle, c, frame, "bayer_rggb8", taps=True)
+        rect = by_topic["/cam0/color_rect/image"]
+        assert rect["encoding"] == "rgb8" and np.array_equal(rect["image"], ref[..., ::-1])
+        assert np.array_equal(by_topic["/cam0/debayered/image"]["image"], t_deb.reshape(h, w, 3)[..., ::-1])
+        assert np.array_equal(by_topic["/cam0/color/image"]["image"], t_col.reshape(h, w, 3)[..., ::-1])
+        info = rect["camera_info"]
+        assert info["header"] == {"stamp": 1.5 + i, "frame_id": "cam0_optical"} and (info["height"], info["width"]) == (h, w)
+        assert info["distortion_model"] == "none" and info["D"] == [0, 0, 0, 0]          # rectified output
+        assert info["K"] == list(cam.pipe.get_rect_camera_matrix().ravel()) and info["P"][:3] == info["K"][:3]
+        dinfo = by_topic["/cam0/color/image"]["camera_info"]
+        assert dinfo["distortion_model"] == "equidistant" and abs(dinfo["K"][2] - 31.63584) < 1e-9
+        for m in msgs:
+            if m["topic"].endswith("slow"):
+                slow_counts[m["topic"]] = slow_counts.get(m["topic"], 0) + 1
+                assert m["camera_info"] is None
+    # skip = 2: frames 0, 3 reach the rect slow topic.  The debayered and colour publishers share one
+    # counter (skipped_images_for_slow_topic_, raw_image_pipeline_ros.cpp:268,286), so together they
+    # publish every third *call*: debayered on frames 0, 3 ... and colour on frames 1, 4 ...
+    assert slow_counts["/cam0/color_rect/image/slow"] == 2
+    assert slow_counts["/cam0/debayered/slow"] + slow_counts["/cam0/color/image/slow"] == 4
+    assert cam.reset_white_balance() == (True, "White balance resetted")
+
+
+@pytest.mark.gpu
+def test_compressed_transport_forces_bgr8(rip_lib):
+    cam = CameraStream({"transport": "compressed", "output_encoding": "passthrough"}, device=0)
+    img = synth.gen_scene_bgr(32, 24, seed=3)
+    msgs = cam.on_image(img, "rgb8")  # the declared encoding is ignored: cv_bridge converted to bgr8
+    final = [m for m in msgs if m["topic"] == "/camera/color/image"][0]
+    assert final["encoding"] == "bgr8" and np.array_equal(final["image"], img)
