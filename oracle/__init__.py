@@ -32,6 +32,7 @@ class Params(C.Structure):
         ("flip_enabled", C.c_int), ("flip_angle", C.c_int),
         ("wb_enabled", C.c_int), ("wb_method", C.c_int),
         ("wb_bright_thr", C.c_double), ("wb_dark_thr", C.c_double),
+        ("wb_percentile", C.c_double),
         ("wb_temporal_consistency", C.c_int),
         ("cc_enabled", C.c_int), ("cc_available", C.c_int),
         ("cc_matrix", C.c_double * 9), ("cc_bias", C.c_double * 3),
@@ -111,6 +112,15 @@ def wb_grayworld(img, thr, return_stats=False):
                             C.c_double(thr), sums, ig)
     if return_stats:
         return img, list(sums), list(ig)
+    return img
+
+
+def wb_simple(img, percentile, return_coeffs=False):
+    img = np.array(img, dtype=np.uint8, order="C", copy=True)
+    ab = (C.c_float * 6)()
+    lib().ripo_wb_simple(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.shape[0] * img.shape[1]), C.c_double(percentile), ab)
+    if return_coeffs:
+        return img, list(ab)
     return img
 
 

@@ -192,6 +192,80 @@ void ripo_wb_grayworld(uint8_t* d, size_t npix, double thr, uint64_t sums_out[3]
 }
 
 /* ------------------------------------------------------------------------------------
+ * "simple" WB -- white_balance.cpp:52-57 -> cv::xphoto::SimpleWB (xphoto/src/
+ * simple_color_balance.cpp, balanceWhiteSimple<uchar>): per channel a two-level tree of 16-bin
+ * histograms over [-0.5, 255.5]; low / high cut where the cumulative count crosses p% / (100-p)%;
+ * then the affine stretch 255 * (x - lo) / (hi - lo) evaluated as one convertTo(alpha, beta) in
+ * float.  Restated literally, including the tree layout in which the second level of bin 0 shares
+ * its storage with the first level (hist[pos + currentBin] with pos = 0 at both).
+ * ---------------------------------------------------------------------------------- */
+void ripo_simple_wb_stretch(const uint32_t hist256[256], int total, float p, float* alpha_out, float* beta_out) {
+  const int bins = 16, depth = 2;
+  int hist[256];
+  memset(hist, 0, sizeof(hist));
+  for (int v = 0; v < 256; v++) {
+    int c = (int)hist256[v];
+    if (!c) continue;
+    /* histogram filling for one value (all c pixels of value v take the same path) */
+    int pos = 0;
+    float minValue = 0.f - 0.5f, maxValue = 255.f + 0.5f;
+    float interval = (float)(maxValue - minValue) / bins;
+    for (int j = 0; j < depth; ++j) {
+      int currentBin = (int)(((float)v - minValue + 1e-4f) / interval);
+      hist[pos + currentBin] += c;
+      pos = (pos + currentBin) * bins;
+      minValue = minValue + currentBin * interval;
+      maxValue = minValue + interval;
+      interval /= bins;
+    }
+    (void)maxValue;
+  }
+  const float s1 = p, s2 = p;
+  int p1 = 0, p2 = bins - 1;
+  int n1 = 0, n2 = total;
+  float minValue = 0.f - 0.5f, maxValue = 255.f + 0.5f;
+  float interval = (maxValue - minValue) / (float)bins;
+  for (int j = 0; j < depth; ++j) {
+    while (p1 < 255 && n1 + hist[p1] < s1 * total / 100.0f) {
+      n1 += hist[p1++];
+      minValue += interval;
+    }
+    p1 *= bins;
+    while (p2 > 0 && n2 - hist[p2] > (100.0f - s2) * total / 100.0f) {
+      n2 -= hist[p2--];
+      maxValue -= interval;
+    }
+    p2 = (p2 + 1) * bins - 1;
+    interval /= bins;
+    if (p1 > 255) p1 = 255; /* the reference would read out of bounds here; unreachable for sane p */
+    if (p2 > 255) p2 = 255;
+  }
+  /* src = (outputMax - outputMin) * (src - minValue) / (maxValue - minValue) + outputMin as a MatExpr:
+   * alpha = 255 * (1/d), beta = (-minValue * 255) * (1/d) + 0 in double, narrowed to float by convertTo */
+  double d = (double)(float)(maxValue - minValue);
+  double inv = 1.0 / d;
+  double alpha = (1.0 * (double)(255.f - 0.f)) * inv;
+  double beta = ((-(double)minValue) * (double)(255.f - 0.f)) * inv + (double)0.f;
+  *alpha_out = (float)alpha;
+  *beta_out = (float)beta;
+}
+
+void ripo_wb_simple(uint8_t* d, size_t npix, double percentile, float ab_out[6]) {
+  for (int c = 0; c < 3; c++) {
+    uint32_t h[256];
+    memset(h, 0, sizeof(h));
+    for (size_t i = 0; i < npix; i++) h[d[i * 3 + c]]++;
+    float a, b;
+    ripo_simple_wb_stretch(h, (int)npix, (float)percentile, &a, &b);
+    for (size_t i = 0; i < npix; i++) d[i * 3 + c] = sat_u8_f((float)d[i * 3 + c] * a + b);
+    if (ab_out) {
+      ab_out[c * 2] = a;
+      ab_out[c * 2 + 1] = b;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------
  * "pca" WB -- white_balance.cpp:73-136, literal.  cv::sum on 32F accumulates in double
  * (all terms are integers < 2^53 so the sum is exact in any order); minMaxLoc maxima;
  * Eigen::Matrix2f filled from doubles (narrowing), inverse() = adjugate / determinant in
@@ -1170,6 +1244,8 @@ int ripo_pipeline(const ripo_params* p, ripo_ccc* ccc, const uint8_t* in, int ro
       ripo_wb_grayworld(img, npix, p->wb_bright_thr, NULL, NULL);
     else if (p->wb_method == 4)
       ripo_wb_pca(img, npix, NULL);
+    else if (p->wb_method == 0)
+      ripo_wb_simple(img, npix, p->wb_percentile, NULL);
     else if (p->wb_method == 3) {
       if (!ccc) {
         free(img); free(tmp); free(keep);
@@ -1180,7 +1256,7 @@ int ripo_pipeline(const ripo_params* p, ripo_ccc* ccc, const uint8_t* in, int ro
       ripo_ccc_balance(ccc, img, r, c, NULL, NULL);
     } else {
       free(img); free(tmp); free(keep);
-      return -4; /* simple / learned: not restated */
+      return -4; /* learned: needs the model compiled into opencv_contrib */
     }
   }
   /* 4. colour calibration (color_calibration.hpp:42-56) */

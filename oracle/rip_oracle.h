@@ -58,6 +58,10 @@ void ripo_flip(const uint8_t* src, int rows, int cols, int cn, int angle, uint8_
 void ripo_wb_grayworld(uint8_t* bgr, size_t npix, double saturation_thr, uint64_t sums_out[3],
                        int igains_out[3]);
 
+/* cv::xphoto::SimpleWB (white_balance.cpp:52-57), p = clipping percentile.  ab_out = {alpha,beta} x B,G,R. */
+void ripo_wb_simple(uint8_t* bgr, size_t npix, double percentile, float ab_out[6]);
+void ripo_simple_wb_stretch(const uint32_t hist256[256], int total, float p, float* alpha_out, float* beta_out);
+
 /* white_balance.cpp:73-136 ("pca").  In place.  coeffs_out = {b_c0,b_c1,r_c0,r_c1}. */
 void ripo_wb_pca(uint8_t* bgr, size_t npix, float coeffs_out[4]);
 
@@ -133,6 +137,7 @@ typedef struct {
   int wb_enabled;
   int wb_method; /* 0 simple(unsupported) 1 grey_world 2 learned(unsupported) 3 ccc 4 pca */
   double wb_bright_thr, wb_dark_thr;
+  double wb_percentile;
   int wb_temporal_consistency;
   int cc_enabled, cc_available;
   double cc_matrix[9], cc_bias[3];

@@ -411,8 +411,10 @@ Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const st
       pl.wb_mode = rip::WB_FLOAT;
     else if (w == "pca")
       pl.wb_mode = rip::WB_PCA;
-    else if (w == "simple" || w == "learned")
-      throw InvalidArgument("White Balance method [" + w + "] (cv::xphoto) is not implemented by the MI355X pipeline; use 'gray_world', 'ccc' or 'pca'");
+    else if (w == "simple")
+      pl.wb_mode = rip::WB_SIMPLE;
+    else if (w == "learned")
+      throw InvalidArgument("White Balance method [learned] (cv::xphoto::LearningBasedWB, a model compiled into opencv_contrib) is not implemented by the MI355X pipeline; use 'simple', 'gray_world', 'ccc' or 'pca'");
     else
       throw InvalidArgument("White Balance method [" + w + "] not supported. Supported algorithms: 'simple', 'gray_world', 'learned', 'ccc', 'pca'");
   }
@@ -445,9 +447,13 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
 
   p->d_wb.reserve(sizeof(rip::FrameWb) * (size_t)n);
   // ---- white-balance statistics ---------------------------------------------------------------
-  if (pl.wb_mode == rip::WB_Q8 || pl.wb_mode == rip::WB_PCA) {
+  if (pl.wb_mode == rip::WB_Q8 || pl.wb_mode == rip::WB_PCA || pl.wb_mode == rip::WB_SIMPLE) {
     p->d_stats.reserve(sizeof(rip::FrameStats) * (size_t)n);
     HIP_CHECK(hipMemsetAsync(p->d_stats.ptr, 0, sizeof(rip::FrameStats) * (size_t)n, p->stream));
+    if (pl.wb_mode == rip::WB_SIMPLE) {
+      p->d_hist.reserve((size_t)n * 768 * sizeof(unsigned));
+      HIP_CHECK(hipMemsetAsync(p->d_hist.ptr, 0, (size_t)n * 768 * sizeof(unsigned), p->stream));
+    }
     rip::StatsParams sp = {};
     sp.src = d_in;
     sp.src_step = in_step;
@@ -461,12 +467,14 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     sp.mode = pl.wb_mode;
     sp.thresh255 = (unsigned)(uint16_t)std::lrintf((float)p->m.wb_bright_thr * 255);
     sp.stats = p->d_stats.as<rip::FrameStats>();
+    sp.hist3 = pl.wb_mode == rip::WB_SIMPLE ? p->d_hist.as<unsigned>() : nullptr;
     {
       ProfScope ps(p, RIP_KERNEL_STATS);
       rip::launch_stats(sp, p->stream);
     }
+    // SimpleWB::setP(clipping_percentile_) (white_balance.cpp:55); total = pixels per channel plane
     rip::launch_wb_finalize(pl.wb_mode, sp.stats, nullptr, nullptr, p->d_tabs.as<rip::DevTables>(), p->d_wb.as<rip::FrameWb>(), n,
-                            p->stream);
+                            p->stream, sp.hist3, (float)p->m.wb_percentile, rows * cols);
   } else if (pl.wb_mode == rip::WB_FLOAT) {
     ensure_ccc(p, pl.mid_rows, pl.mid_cols);
     p->d_hist.reserve((size_t)n * 65536 * sizeof(unsigned));

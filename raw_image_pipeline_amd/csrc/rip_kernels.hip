@@ -205,6 +205,11 @@ __device__ __forceinline__ void apply_wb(int mode, const FrameWb& w, int& b, int
     b = sat_round_u8((float)b * w.fg[0]);
     g = sat_round_u8((float)g * w.fg[1]);
     r = sat_round_u8((float)r * w.fg[2]);
+  } else if (mode == WB_SIMPLE) {
+    // SimpleWB's stretch: convertTo(8U, alpha, beta) = saturate(float(x) * alpha + beta), no FMA
+    b = sat_round_u8((float)b * w.fg[0] + w.pca[0]);
+    g = sat_round_u8((float)g * w.fg[1] + w.pca[1]);
+    r = sat_round_u8((float)r * w.fg[2] + w.pca[2]);
   } else if (mode == WB_PCA) {
     float fb = (float)b, fr = (float)r;
     float b2 = fb * fb, r2 = fr * fr;
@@ -775,8 +780,13 @@ struct StatAcc {
   unsigned m[3];
 };
 
-__device__ __forceinline__ void stat_add(const StatsParams& p, int b, int g, int r, StatAcc& a) {
-  if (p.mode == WB_Q8) {
+__device__ __forceinline__ void stat_add(const StatsParams& p, int b, int g, int r, StatAcc& a, unsigned* s_hist) {
+  if (p.mode == WB_SIMPLE) {
+    // SimpleWB: per-channel 256-bin histograms, privatised in LDS
+    atomicAdd(&s_hist[b], 1u);
+    atomicAdd(&s_hist[256 + g], 1u);
+    atomicAdd(&s_hist[512 + r], 1u);
+  } else if (p.mode == WB_Q8) {
     // GrayworldWB calculateChannelSums: skip when (max-min)*255 > thresh255*max
     unsigned mn = (unsigned)min(b, min(g, r)), mx = (unsigned)max(b, max(g, r));
     if ((mx - mn) * 255u > p.thresh255 * mx) return;
@@ -795,7 +805,19 @@ __device__ __forceinline__ void stat_add(const StatsParams& p, int b, int g, int
   }
 }
 
-__device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, FrameStats* out) {
+__device__ __forceinline__ void stat_hist_init(const StatsParams& p, unsigned* s_hist) {
+  if (p.mode != WB_SIMPLE) return;
+  for (int i = threadIdx.x; i < 768; i += kBlock) s_hist[i] = 0u;
+  __syncthreads();
+}
+
+__device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, FrameStats* out, unsigned* s_hist, int frame) {
+  if (p.mode == WB_SIMPLE) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += kBlock)
+      if (s_hist[i]) atomicAdd(&p.hist3[(size_t)frame * 768 + i], s_hist[i]);
+    return;
+  }
   __shared__ unsigned sh[8][kBlock / 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -821,6 +843,8 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
 }
 
 __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, ItemMap im, int items_per_frame) {
+  __shared__ unsigned s_hist[768];
+  stat_hist_init(p, s_hist);
   const int frame = blockIdx.y;
   const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
   StatAcc a = {};
@@ -837,13 +861,15 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, ItemM
 #pragma unroll
       for (int lx = 0; lx < 4; lx++)
         stat_add(p, (int)((rowpx[ly].b >> (8 * lx)) & 0xFFu), (int)((rowpx[ly].g >> (8 * lx)) & 0xFFu),
-                 (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a);
+                 (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a, s_hist);
   }
-  stat_flush(p, a, p.stats + frame);
+  stat_flush(p, a, p.stats + frame, s_hist, frame);
 }
 
 // colour input (bgr8 / rgb8), 4 px per lane
 __global__ __launch_bounds__(kBlock) void stats_color_kernel(StatsParams p, ItemMap im, int items_per_frame) {
+  __shared__ unsigned s_hist[768];
+  stat_hist_init(p, s_hist);
   const int frame = blockIdx.y;
   const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
   const bool rgb = p.src_kind == SRC_RGB;
@@ -855,12 +881,14 @@ __global__ __launch_bounds__(kBlock) void stats_color_kernel(StatsParams p, Item
     int q[4][3];
     unpack12(in, rgb, q);
 #pragma unroll
-    for (int k = 0; k < 4; k++) stat_add(p, q[k][0], q[k][1], q[k][2], a);
+    for (int k = 0; k < 4; k++) stat_add(p, q[k][0], q[k][1], q[k][2], a, s_hist);
   }
-  stat_flush(p, a, p.stats + frame);
+  stat_flush(p, a, p.stats + frame, s_hist, frame);
 }
 
 __global__ __launch_bounds__(kBlock) void stats_generic_kernel(StatsParams p) {
+  __shared__ unsigned s_hist[768];
+  stat_hist_init(p, s_hist);
   const int frame = blockIdx.y;
   SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
   const long long npix = (long long)p.rows * p.cols;
@@ -869,9 +897,9 @@ __global__ __launch_bounds__(kBlock) void stats_generic_kernel(StatsParams p) {
     int y = (int)(i / p.cols), x = (int)(i - (long long)y * p.cols);
     int b, g, r;
     fetch_src(s, y, x, b, g, r);
-    stat_add(p, b, g, r, a);
+    stat_add(p, b, g, r, a, s_hist);
   }
-  stat_flush(p, a, p.stats + frame);
+  stat_flush(p, a, p.stats + frame, s_hist, frame);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -887,7 +915,8 @@ __device__ __forceinline__ void solve2(float m00, float m01, float m10, float m1
 }
 
 __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* st,
-                                   const DevTables* tabs, FrameWb* out, int n_frames) {
+                                   const DevTables* tabs, FrameWb* out, int n_frames, const unsigned* simple_hist,
+                                   float simple_p, int simple_total) {
   if (mode == WB_FLOAT) {
     // ccc: temporal filter is sequential over the frames of the stream
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -948,6 +977,55 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
   int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_frames) return;
   FrameWb w = {};
+  if (mode == WB_SIMPLE) {
+    // cv::xphoto::SimpleWB (simple_color_balance.cpp balanceWhiteSimple<uchar>), restated literally:
+    // two-level tree of 16-bin histograms whose second level of bin 0 aliases the first level
+    const unsigned* h3 = simple_hist + (size_t)f * 768;
+    for (int c = 0; c < 3; c++) {
+      const unsigned* hist256 = h3 + c * 256;
+      int hist[256];
+      for (int i = 0; i < 256; i++) hist[i] = 0;
+      for (int v = 0; v < 256; v++) {
+        const int cnt = (int)hist256[v];
+        if (!cnt) continue;
+        int pos = 0;
+        float minValue = 0.f - 0.5f;
+        float interval = (255.5f - minValue) / 16;
+        for (int j = 0; j < 2; ++j) {
+          const int currentBin = (int)(((float)v - minValue + 1e-4f) / interval);
+          hist[pos + currentBin] += cnt;
+          pos = (pos + currentBin) * 16;
+          minValue = minValue + currentBin * interval;
+          interval /= 16;
+        }
+      }
+      const float s1 = simple_p, s2 = simple_p;
+      int p1 = 0, p2 = 15, n1 = 0, n2 = simple_total;
+      float minValue = 0.f - 0.5f, maxValue = 255.f + 0.5f;
+      float interval = (maxValue - minValue) / 16.0f;
+      for (int j = 0; j < 2; ++j) {
+        while (p1 < 255 && (float)(n1 + hist[p1]) < s1 * (float)simple_total / 100.0f) {
+          n1 += hist[p1++];
+          minValue += interval;
+        }
+        p1 *= 16;
+        while (p2 > 0 && (float)(n2 - hist[p2]) > (100.0f - s2) * (float)simple_total / 100.0f) {
+          n2 -= hist[p2--];
+          maxValue -= interval;
+        }
+        p2 = (p2 + 1) * 16 - 1;
+        interval /= 16;
+        if (p1 > 255) p1 = 255;
+        if (p2 > 255) p2 = 255;
+      }
+      const double d = (double)(maxValue - minValue);
+      const double inv = 1.0 / d;
+      w.fg[c] = (float)((1.0 * 255.0) * inv);
+      w.pca[c] = (float)(((-(double)minValue) * 255.0) * inv + 0.0);
+    }
+    out[f] = w;
+    return;
+  }
   const FrameStats& fs = stats[f];
   if (mode == WB_Q8) {
     // GrayworldWBImpl::balanceWhite + applyChannelGains
@@ -1499,6 +1577,7 @@ void launch_fast_wb(const ChainParams& p, const ItemMap& im, int items, dim3 gri
     case WB_Q8: launch_fast<BITS, WB_Q8>(p, im, items, grid, stream); break;
     case WB_FLOAT: launch_fast<BITS, WB_FLOAT>(p, im, items, grid, stream); break;
     case WB_PCA: launch_fast<BITS, WB_PCA>(p, im, items, grid, stream); break;
+    case WB_SIMPLE: launch_fast<BITS, WB_SIMPLE>(p, im, items, grid, stream); break;
     default: launch_fast<BITS, WB_NONE>(p, im, items, grid, stream); break;
   }
 }
@@ -1590,13 +1669,15 @@ void launch_ccc_estimate(const CccParams& p, hipStream_t stream) {
 }
 
 void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
-                        const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream) {
+                        const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream, const unsigned* simple_hist,
+                        float simple_p, int simple_total) {
   if (n_frames <= 0) return;
   if (mode == WB_FLOAT) {
-    hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, stream, mode, stats, ccc_argmax, ccc_state, tabs, out, n_frames);
+    hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, stream, mode, stats, ccc_argmax, ccc_state, tabs, out, n_frames,
+                       simple_hist, simple_p, simple_total);
   } else {
     hipLaunchKernelGGL(wb_finalize_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, mode, stats, ccc_argmax,
-                       ccc_state, tabs, out, n_frames);
+                       ccc_state, tabs, out, n_frames, simple_hist, simple_p, simple_total);
   }
 }
 

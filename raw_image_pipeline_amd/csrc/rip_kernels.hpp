@@ -11,7 +11,7 @@
 namespace rip {
 
 enum SrcKind : int { SRC_BAYER = 0, SRC_BGR = 1, SRC_RGB = 2, SRC_MONO = 3 };
-enum WbMode : int { WB_NONE = 0, WB_Q8 = 1, WB_FLOAT = 2, WB_PCA = 3 };
+enum WbMode : int { WB_NONE = 0, WB_Q8 = 1, WB_FLOAT = 2, WB_PCA = 3, WB_SIMPLE = 4 };
 // Stage bits of the fused chain (compile-time specialisation key of the fast kernel)
 enum StageBits : int { ST_CC = 1, ST_GAMMA = 2, ST_VIG = 4, ST_HSV = 8 };
 
@@ -35,8 +35,8 @@ struct DevTables {
 // Per-frame white-balance parameters, produced on the device by the statistics kernels.
 struct FrameWb {
   int q8[3];      // grey-world Q8 gains (B,G,R)
-  float fg[3];    // float gains (B,G,R), ccc
-  float pca[4];   // b_c0, b_c1, r_c0, r_c1
+  float fg[3];    // float gains (B,G,R): ccc; SimpleWB alpha
+  float pca[4];   // pca: b_c0, b_c1, r_c0, r_c1; SimpleWB: beta (B,G,R)
   int uv[2];      // ccc (x, y) used for the gains
   int uv_raw[2];  // ccc argmax before temporal filtering
   int pad[2];
@@ -96,6 +96,7 @@ struct StatsParams {
   int mode;  // WB_Q8: grey-world sums; WB_PCA: pca sums
   unsigned thresh255;  // grey-world: cvRound(255 * thr)
   FrameStats* stats;   // [n_frames], zeroed
+  unsigned* hist3;     // WB_SIMPLE: [n_frames][3][256] per-channel histograms, zeroed
 };
 
 struct CccGeom {
@@ -161,7 +162,8 @@ void launch_stats(const StatsParams& p, hipStream_t stream);
 void launch_ccc_estimate(const CccParams& p, hipStream_t stream);
 // Turns raw statistics into FrameWb (grey-world / pca) or runs the ccc temporal filter + gains.
 void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
-                        const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream);
+                        const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream,
+                        const unsigned* simple_hist = nullptr, float simple_p = 0.f, int simple_total = 0);
 void launch_remap(const RemapParams& p, hipStream_t stream);
 // Which code path launch_chain would pick (for tests / DESIGN.md): 1 fast, 0 generic.
 int chain_uses_fast_path(const ChainParams& p);

@@ -6,7 +6,7 @@ from raw_image_pipeline_amd import synth
 
 DEFAULTS = dict(
     flip=False, flip_angle=0,
-    wb=False, wb_method="grey_world", wb_bright=0.8, wb_dark=0.2, wb_temporal=False,
+    wb=False, wb_method="grey_world", wb_bright=0.8, wb_dark=0.2, wb_temporal=False, wb_percentile=10.0,
     cc=False, cc_matrix=None, cc_bias=(0.0, 0.0, 0.0),
     gamma=False, gamma_k=0.8, gamma_method="custom",
     vig=False, vig_params=(1.5, 1e-3, 1e-6),
@@ -30,6 +30,7 @@ def configure(pipe, c):
     pipe.set_white_balance(c["wb"])
     pipe.set_white_balance_method(c["wb_method"])
     pipe.set_white_balance_saturation_threshold(c["wb_bright"], c["wb_dark"])
+    pipe.set_white_balance_percentile(c["wb_percentile"])
     pipe.set_white_balance_temporal_consistency(c["wb_temporal"])
     pipe.set_color_calibration(c["cc"])
     pipe.set_color_calibration_matrix(c["cc_matrix"])
@@ -63,6 +64,7 @@ def oracle_params(O, c, keep):
     p.wb_enabled = int(c["wb"])
     p.wb_method = O.WB_METHODS.get(c["wb_method"], -1)
     p.wb_bright_thr, p.wb_dark_thr = c["wb_bright"], c["wb_dark"]
+    p.wb_percentile = c["wb_percentile"]
     p.wb_temporal_consistency = int(c["wb_temporal"])
     p.cc_enabled, p.cc_available = int(c["cc"]), 1
     m32 = np.asarray(c["cc_matrix"], np.float64)

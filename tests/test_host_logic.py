@@ -128,7 +128,7 @@ def test_query_output_and_encoding_rules(host_pipe):
     with pytest.raises(ValueError, match="valid pattern but is not supported"):
         p.query_output(48, 64, 1, "bayer_rggb16")
     p.set_white_balance(True)
-    p.set_white_balance_method("simple")
+    p.set_white_balance_method("learned")
     with pytest.raises(ValueError, match="not implemented"):
         p.query_output(48, 64, 1, "bayer_gbrg8")
     p.set_white_balance_method("nonsense")

@@ -109,6 +109,25 @@ def test_grayworld_uniform_grey_is_identity(oracle):
     assert np.array_equal(oracle.wb_grayworld(img, 0.8), img)
 
 
+# ---- simple WB (xphoto SimpleWB) ------------------------------------------------------------------------------
+def test_simple_wb_percentile_stretch(oracle):
+    # one channel plane 0..199 uniformly (each value equally often): p = 10 % cuts at 20 and 180
+    vals = np.repeat(np.arange(200, dtype=np.uint8), 5)
+    img = np.stack([vals, vals, vals], axis=-1).reshape(25, 40, 3)
+    out, ab = oracle.wb_simple(img, 10.0, return_coeffs=True)
+    # Hand run of balanceWhiteSimple's tree (16 x 16 bins; the second level of first-level bin 0 aliases
+    # hist[0..15], so those entries hold 80 + 5 / 40 + 5 / 5 counts):
+    #   level 0: low  85 < 100 -> skip bin 0 (min 15.5), 170 >= 100 stop;  high: 995, 990, 985, 940 > 900 -> max 191.5
+    #   level 1: low  90, 95 < 100 -> min 17.5;  high: 935 ... 905 > 900 (7 steps) -> max 184.5
+    # (an alias-free tree would give 19.5 / 179.5)
+    for c in range(3):
+        a, b = ab[2 * c], ab[2 * c + 1]
+        assert abs(-b / a - 17.5) < 1e-3 and abs((255 - b) / a - 184.5) < 1e-3
+    assert out.min() == 0 and out.max() == 255
+    mid = img[..., 0] == 100
+    assert (out[..., 0][mid] == int(np.rint(np.float32(100) * np.float32(ab[0]) + np.float32(ab[1])))).all()
+
+
 # ---- colour matrix (color_calibration.cpp:91-104) -------------------------------------------------------------
 def test_color_matrix_rounding_and_saturation(oracle):
     img = np.array([[[10, 20, 30], [255, 255, 255], [1, 1, 1]]], np.uint8)

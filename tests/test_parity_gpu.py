@@ -87,6 +87,14 @@ def test_white_balance_statistics_methods(gpu_pipe, oracle, method, kind, size):
              what="wb %s %s" % (method, kind))
 
 
+@pytest.mark.parametrize("percentile", [1.0, 10.0, 20.0, 45.0])
+@pytest.mark.parametrize("kind,size", [("scene", (128, 96)), ("uniform", (64, 48)), ("scene", (51, 33))])
+def test_simple_white_balance(gpu_pipe, oracle, percentile, kind, size):
+    frame = synth.gen_frame(size[0], size[1], "bayer_gbrg8", seed=7, kind=kind)
+    run_both(gpu_pipe, oracle, cfg(wb=True, wb_method="simple", wb_percentile=percentile), frame, "bayer_gbrg8", TOL_DECLARED,
+             what="simple wb p=%g %s" % (percentile, kind))
+
+
 def test_grey_world_gains_match_oracle(gpu_pipe, oracle):
     frame = synth.gen_frame(128, 96, "bayer_grbg8", seed=9, kind="scene")
     configure(gpu_pipe, cfg(wb=True, wb_method="grey_world", wb_bright=0.9))
