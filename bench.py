@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--workload", default="config2", choices=["config2", "chain", "config3", "config5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true", help="skip the streaming copy/read microbenchmark")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -153,6 +154,24 @@ def cpu_baseline(width, height, pattern, seconds):
                       % (done, width, height, pattern, cores, el)}
 
 
+def hbm_probe(torch, nbytes=1 << 30, reps=10):
+    """Streaming copy and read-only rates of this GPU (torch elementwise kernels), GB/s of bytes moved."""
+    src = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda").fill_(1)
+    dst = torch.empty_like(src)
+    res = {}
+    for name, fn, moved in (("copy_GBps", lambda: dst.copy_(src), 2 * nbytes), ("read_GBps", lambda: src.sum(), nbytes)):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = round(moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    return res
+
+
 def main():
     args = parse_args()
     import torch
@@ -232,6 +251,11 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if world == 1 and not args.no_hbm_probe:
+        # what this box's HBM actually delivers to a plain streaming kernel, beside the 8 TB/s spec
+        del out
+        probe = hbm_probe(torch)
+        roofline["empirical"] = dict(probe, frac_of_copy=round(achieved / probe["copy_GBps"], 4) if probe["copy_GBps"] else None)
     result = {
         "metric": "frames/sec at 2448x2048 bayer_rggb8 full chain; achieved HBM GB/s vs roofline",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

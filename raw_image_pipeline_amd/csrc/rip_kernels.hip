@@ -1566,6 +1566,14 @@ bool bayer_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, i
          (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
 }
 
+// grid-size tunables (persistent workgroups per launch), overridable from the environment for experiments
+int tune_env(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  if (!e || !*e) return dflt;
+  const int v = std::atoi(e);
+  return v >= 8 ? v / 8 * 8 : (v > 0 ? v : dflt);
+}
+
 template <int BITS, int WB>
 void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
   hipLaunchKernelGGL((chain_fast_kernel<BITS, WB>), grid, dim3(kBlock), 0, stream, p, im, items);
@@ -1610,8 +1618,9 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     const int items = (p.rows / 2) * (p.cols / 4);
     const long long chunks = (long long)((items + kBlock - 1) / kBlock);
     // persistent grid: at most 256 CUs x 8 workgroups, a multiple of 8 (one share per XCD)
-    int blocks = (int)std::min<long long>(2048, (chunks + 7) / 8 * 8);
-    const int groups = std::max(1, std::min(p.n_frames, 2048 / blocks));
+    const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
+    int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
+    const int groups = std::max(1, std::min(p.n_frames, cap / blocks));
     dim3 grid(blocks, groups);
     switch (p.stage_bits & 15) {
 #define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream); break;
@@ -1641,7 +1650,7 @@ void launch_stats(const StatsParams& p, hipStream_t stream) {
     ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
     const int items = (p.rows / 2) * (p.cols / 4);
     // keep >= 1 block per 2^20 items so the 32-bit per-thread partial sums cannot overflow
-    int per_frame = grid_blocks_for(items, std::max(8, 2048 / std::max(1, std::min(p.n_frames, 16))));
+    int per_frame = grid_blocks_for(items, std::max(8, tune_env("RIP_STATS_BLOCKS", 2048) / std::max(1, std::min(p.n_frames, 16))));
     per_frame = std::max(per_frame, (int)((items + (1 << 20) - 1) >> 20));
     hipLaunchKernelGGL(stats_fast_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
     return;
@@ -1700,7 +1709,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
   if (const char* e = std::getenv("RIP_REMAP_PRE")) pre = std::min(pre, std::atoi(e));
   q.double_buffer = pre > 0 ? 1 : 0;
   const unsigned lds = q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes;
-  const int per_cu = std::max(1, std::min(8, (int)((160u * 1024u) / (lds + 256u))));
+  const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
   int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
   blocks = std::max(8, blocks / 8 * 8);
   const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too

@@ -25,7 +25,7 @@ FETCH_FACTOR = {"stats": 1.0, "chain": 1.0, "remap": 2.0, "ccc": 1.0}
 def run_pass(out_dir, name, counters, workload):
     d = os.path.join(out_dir, "pmc_%s_%s" % (workload, name))
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", workload]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--workload", workload]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     rows = []
@@ -67,7 +67,7 @@ def main():
         json.dump(result, f, indent=1, sort_keys=True)
     with open(os.path.join(out_dir, "pmc_summary.txt"), "w") as f:
         f.write("# HBM traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes) of\n"
-                "# `bench.py --steps 4 --warmup 1 --no-cpu-baseline --workload <wl>` (64 frames per launch)\n")
+                "# `bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-probe --workload <wl>` (64 frames per launch)\n")
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
