@@ -159,7 +159,7 @@ def hbm_probe(torch, nbytes=1 << 30, reps=10):
     src = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda").fill_(1)
     dst = torch.empty_like(src)
     res = {}
-    for name, fn, moved in (("copy_GBps", lambda: dst.copy_(src), 2 * nbytes), ("read_GBps", lambda: src.sum(), nbytes)):
+    for name, fn, moved in (("copy_GBps", lambda: dst.copy_(src), 2 * nbytes), ("read_GBps", lambda: src.view(torch.int64).sum(), nbytes)):
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

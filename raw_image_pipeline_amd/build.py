@@ -12,7 +12,7 @@ OUT = os.path.join(HERE, "librip_hip.so")
 SOURCES = ["rip_kernels.hip", "rip_host.cpp", "rip_api.cpp"]
 HEADERS = ["rip_kernels.hpp", "rip_host.hpp", os.path.join("..", "..", "include", "rip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
+         "-fvisibility=hidden", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
 
 
 def hipcc():

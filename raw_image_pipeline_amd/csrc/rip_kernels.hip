@@ -47,6 +47,9 @@ __device__ __forceinline__ unsigned umulhi24(unsigned a, unsigned b) {
   return (unsigned)(((unsigned long long)(a & 0xffffffu) * (unsigned long long)(b & 0xffffffu)) >> 32);
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+// Put inside a wave-uniform `if` body: the empty volatile asm cannot be speculated, so hipcc keeps the
+// scalar branch instead of computing both sides and selecting per lane with v_cndmask.
+__device__ __forceinline__ void keep_branch() { asm volatile(""); }
 
 struct SrcView {
   const uint8_t* base;
@@ -227,9 +230,13 @@ __device__ __forceinline__ void apply_cc(const ChainParams& p, int& b, int& g, i
   float fb = (float)b, fg = (float)g, fr = (float)r;
   float o[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) {
-    float t = fb * p.cc_m[c * 3] + fg * p.cc_m[c * 3 + 1] + fr * p.cc_m[c * 3 + 2];
-    o[c] = t + p.cc_bias[c];
+  for (int c = 0; c < 3; c++) o[c] = fb * p.cc_m[c * 3] + fg * p.cc_m[c * 3 + 1] + fr * p.cc_m[c * 3 + 2];
+  // t + 0.0f == t (up to the sign of zero, which the saturating conversion drops): the usual all-zero
+  // bias costs nothing; the test is wave-uniform (kernel arguments)
+  if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
+    keep_branch();
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = o[c] + p.cc_bias[c];
   }
   b = sat_round_u8(o[0]);
   g = sat_round_u8(o[1]);
@@ -306,14 +313,17 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
   // but those values clamp to the same end of the range anyway
   const float ta = __builtin_fmaf(fX - fY, 500.0f, 4194304.5f);
   const float tb2 = __builtin_fmaf(fY - fZ, 200.0f, 4194304.5f);
-  int a = (int)(__float_as_uint(__builtin_fmaf(ta, 1.0f / 32768.0f, kMagic)) - kMagicBits);
-  int bb = (int)(__float_as_uint(__builtin_fmaf(tb2, 1.0f / 32768.0f, kMagic)) - kMagicBits);
-  a = clampi(a, 0, 255);
-  bb = clampi(bb, 0, 255);
+  // OpenCV saturates a and b to [0, 255]; over all 2^24 inputs they stay inside [42, 226] and [20, 223]
+  // (exhaustive check: tests/test_oracle_known_answers.py::test_lab_ab_never_saturate), so the clamp is dead.
+  // abits = kMagicBits + a: the 24-bit multiply reads 0x400000 + a, the constant takes 0x400000 * K back
+  // (mod 2^32), leaving a * K + rounding in one v_mad_u32_u24.
+  const unsigned abits = __float_as_uint(__builtin_fmaf(ta, 1.0f / 32768.0f, kMagic));
+  const unsigned bbits = __float_as_uint(__builtin_fmaf(tb2, 1.0f / 32768.0f, kMagic));
+  constexpr unsigned kA = 5u * 53687u, kB = 41943u;
   const unsigned yf = tb.yf(L);
   const int y = (int)(yf & 0xffffu), ify = (int)(yf >> 16);
-  const int adiv = ((mul24(a, 5 * 53687) + (1 << 7)) >> 13) - 128 * 16384 / 500;
-  const int bdiv = ((mul24(bb, 41943) + (1 << 4)) >> 9) - 128 * 16384 / 200 + 1;
+  const int adiv = (int)((__umul24(abits, kA) + ((1u << 7) - 0x400000u * kA)) >> 13) - 128 * 16384 / 500;
+  const int bdiv = (int)((__umul24(bbits, kB) + ((1u << 4) - 0x400000u * kB)) >> 9) - 128 * 16384 / 200 + 1;
   int x, z;
   ab_to_xz_pair(ify + adiv, ify - bdiv, x, z);
   const int bo = mad24(inv[2], z, mad24(inv[1], y, mad24(inv[0], x, 1 << 13))) >> 14;
@@ -449,17 +459,40 @@ struct Window {
   }
 };
 
-__device__ __forceinline__ void load_window(const uint8_t* frame, unsigned step, int rows, int cols, int y0, int x0,
-                                            Window& win) {
+// Frames are addressed through buffer resources (uniform base in SGPRs, 32-bit per-lane byte offset
+// in one VGPR): the frame base changes per iteration of the frames loop on the scalar unit, and no
+// 64-bit per-lane address arithmetic is issued on the VALU.  A frame is < 4 GiB (checked by the
+// launchers); reads past `bytes` return 0.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// byte offsets of the window dwords inside a frame: rows y0-1 .. y0+2 (clamped), left dword and
+// centre dword (the right dword is centre + 4 except at the right image edge, where it is the centre)
+struct WindowOffsets {
+  unsigned left[4], centre[4];
+  unsigned right_delta;  // 4, or 0 at the right edge
+};
+__device__ __forceinline__ WindowOffsets window_offsets(unsigned step, int rows, int cols, int y0, int x0) {
+  WindowOffsets o;
   const int xl = x0 >= 4 ? x0 - 4 : x0;
-  const int xr = x0 + 4 < cols ? x0 + 4 : x0;
+  o.right_delta = x0 + 4 < cols ? 4u : 0u;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int y = clampi(y0 - 1 + r, 0, rows - 1);
     const unsigned row = __umul24((unsigned)y, step);  // 32-bit offsets: a frame is < 4 GiB, a row < 16 MiB
-    win.w[r][0] = *reinterpret_cast<const uint32_t*>(frame + (row + (unsigned)xl));
-    win.w[r][1] = *reinterpret_cast<const uint32_t*>(frame + (row + (unsigned)x0));
-    win.w[r][2] = *reinterpret_cast<const uint32_t*>(frame + (row + (unsigned)xr));
+    o.left[r] = row + (unsigned)xl;
+    o.centre[r] = row + (unsigned)x0;
+  }
+  return o;
+}
+__device__ __forceinline__ void load_window(__amdgpu_buffer_rsrc_t frame, const WindowOffsets& o, Window& win) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    win.w[r][0] = __builtin_amdgcn_raw_buffer_load_b32(frame, (int)o.left[r], 0, 0);
+    win.w[r][1] = __builtin_amdgcn_raw_buffer_load_b32(frame, (int)o.centre[r], 0, 0);
+    win.w[r][2] = __builtin_amdgcn_raw_buffer_load_b32(frame, (int)(o.centre[r] + o.right_delta), 0, 0);
   }
 }
 
@@ -476,13 +509,13 @@ __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b)
 template <int RY, int RX>
 __device__ __forceinline__ void debayer_swar(const Window& win, Planar (&out)[2]) {
   constexpr uint32_t M8 = 0x00FF00FFu;
-  uint32_t hs_lo[4], hs_hi[4], c_lo[4], c_hi[4];
+  uint32_t hs_lo[4], hs_hi[4], c_lo[4], c_hi[4], wm[4], wp[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const uint32_t wm = __builtin_amdgcn_alignbyte(win.w[r][1], win.w[r][0], 3);  // columns x0-1 .. x0+2
-    const uint32_t wp = __builtin_amdgcn_alignbyte(win.w[r][2], win.w[r][1], 1);  // columns x0+1 .. x0+4
-    hs_lo[r] = (wm & M8) + (wp & M8);  // left + right neighbour, pixels 0 and 2
-    hs_hi[r] = ((wm >> 8) & M8) + ((wp >> 8) & M8);  // pixels 1 and 3
+    wm[r] = __builtin_amdgcn_alignbyte(win.w[r][1], win.w[r][0], 3);  // columns x0-1 .. x0+2
+    wp[r] = __builtin_amdgcn_alignbyte(win.w[r][2], win.w[r][1], 1);  // columns x0+1 .. x0+4
+    hs_lo[r] = (wm[r] & M8) + (wp[r] & M8);  // left + right neighbour, pixels 0 and 2
+    hs_hi[r] = ((wm[r] >> 8) & M8) + ((wp[r] >> 8) & M8);  // pixels 1 and 3
     c_lo[r] = win.w[r][1] & M8;
     c_hi[r] = (win.w[r][1] >> 8) & M8;
   }
@@ -490,9 +523,9 @@ __device__ __forceinline__ void debayer_swar(const Window& win, Planar (&out)[2]
 #pragma unroll
   for (int ly = 0; ly < 2; ly++) {
     const int cr = ly + 1;
-    const uint32_t H = (((hs_lo[cr] + 0x00010001u) >> 1) & M8) | ((((hs_hi[cr] + 0x00010001u) >> 1) & M8) << 8);
-    const uint32_t V = (((c_lo[cr - 1] + c_lo[cr + 1] + 0x00010001u) >> 1) & M8) |
-                       ((((c_hi[cr - 1] + c_hi[cr + 1] + 0x00010001u) >> 1) & M8) << 8);
+    // two-tap averages (a + b + 1) >> 1 of all four byte lanes in one v_lerp_u8
+    const uint32_t H = __builtin_amdgcn_lerp(wm[cr], wp[cr], 0x01010101u);
+    const uint32_t V = __builtin_amdgcn_lerp(win.w[cr - 1][1], win.w[cr + 1][1], 0x01010101u);
     const uint32_t X4 = (((hs_lo[cr] + c_lo[cr - 1] + c_lo[cr + 1] + 0x00020002u) >> 2) & M8) |
                         ((((hs_hi[cr] + c_hi[cr - 1] + c_hi[cr + 1] + 0x00020002u) >> 2) & M8) << 8);
     const uint32_t D4 = (((hs_lo[cr - 1] + hs_lo[cr + 1] + 0x00020002u) >> 2) & M8) |
@@ -571,6 +604,20 @@ __device__ __forceinline__ void store12(uint8_t* ptr, const Pack3& v) {
   *reinterpret_cast<uint3*>(ptr) = u;
 }
 
+__device__ __forceinline__ void store12(__amdgpu_buffer_rsrc_t frame, unsigned off, const Pack3& v) {
+  u32x3 u = {v.a, v.b, v.c};
+  __builtin_amdgcn_raw_buffer_store_b96(u, frame, (int)off, 0, 0);
+}
+
+// Grey-world applyChannelGains (x * q) >> 8 on four packed bytes.  q <= 256 (the gains are normalised
+// by the largest one), so the products of the even and of the odd bytes stay inside their 16-bit
+// lanes and one 24-bit multiply serves two pixels.
+__device__ __forceinline__ uint32_t gains_q8_swar(uint32_t v, unsigned q) {
+  const uint32_t pe = __umul24(v & 0x00FF00FFu, q);
+  const uint32_t po = __umul24((v >> 8) & 0x00FF00FFu, q);
+  return bfi32(0xFF00FF00u, po, pe >> 8);
+}
+
 // item index -> (row pair, 4-px group) without an integer division per item
 struct ItemMap {
   int groups_per_row;
@@ -633,31 +680,42 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
 #pragma unroll
       for (int k = 0; k < 4; k++) mask[ly][k] = (BITS & ST_VIG) ? vignette_mask(p, yd, xbase + k) : 1.0f;
     }
+    const WindowOffsets wo = window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0);
+    const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
+    const unsigned dst_bytes = __umul24((unsigned)(p.drows - 1), (unsigned)p.dst_step) + (unsigned)p.dcols * 3u;
+    const unsigned tap_bytes = __umul24((unsigned)p.drows, (unsigned)p.dcols) * 3u;
     for (int frame = f_begin; frame < f_end; frame++) {
-      const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
-      uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
-      uint8_t* tap = p.tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr;
+      const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
+      const __amdgpu_buffer_rsrc_t dst = frame_rsrc(p.dst + (size_t)frame * p.dst_frame_stride, dst_bytes);
+      const bool has_tap = p.tap != nullptr;
+      const __amdgpu_buffer_rsrc_t tap = frame_rsrc(has_tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr, has_tap ? tap_bytes : 0u);
       FrameWb w;
       if (WB != WB_NONE) w = p.wb[frame];
       Window win;
-      load_window(src, (unsigned)p.src_step, p.rows, p.cols, y0, x0, win);
+      load_window(src, wo, win);
       Planar rowpx[2];
       debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
 #pragma unroll
       for (int ly = 0; ly < 2; ly++) {
         Planar v = rowpx[ly];
         if (flip180) {  // the group is written mirrored: reverse the four pixels
+          keep_branch();
           v.b = __builtin_bswap32(v.b);
           v.g = __builtin_bswap32(v.g);
           v.r = __builtin_bswap32(v.r);
         }
         Pack3 raw;
-        const bool need_raw = tap != nullptr || (BITS == 0 && WB == WB_NONE);
+        const bool need_raw = has_tap || (BITS == 0 && WB == WB_NONE);
         if (need_raw) interleave4(v, raw.a, raw.b, raw.c);
-        if (tap) store12(tap + tap_off[ly], raw);
+        if (has_tap) store12(tap, tap_off[ly], raw);
         if (BITS == 0 && WB == WB_NONE) {
-          store12(dst + dst_off[ly], raw);  // pure demosaic: no per-pixel stage
+          store12(dst, dst_off[ly], raw);  // pure demosaic: no per-pixel stage
           continue;
+        }
+        if (WB == WB_Q8) {  // grey-world gains on the packed bytes, two pixels per multiply
+          v.b = gains_q8_swar(v.b, (unsigned)w.q8[0]);
+          v.g = gains_q8_swar(v.g, (unsigned)w.q8[1]);
+          v.r = gains_q8_swar(v.r, (unsigned)w.q8[2]);
         }
         int q[4][3];
 #pragma unroll
@@ -665,9 +723,9 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
           q[k][0] = (int)((v.b >> (8 * k)) & 0xFFu);
           q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
           q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
-          pointwise<BITS, WB>(p, w, tb, s_fwd, s_inv, mask[ly][k], q[k][0], q[k][1], q[k][2]);
+          pointwise<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, s_fwd, s_inv, mask[ly][k], q[k][0], q[k][1], q[k][2]);
         }
-        store12(dst + dst_off[ly], pack4(q));
+        store12(dst, dst_off[ly], pack4(q));
       }
     }
   }
@@ -842,26 +900,62 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
   }
 }
 
+// Grey-world statistics of four planar pixels, two pixels per instruction: the bytes are widened to
+// 16-bit lanes; max/min with v_pk_max/min_u16; both sides of the saturation test
+// (max - min) * 255 > thresh255 * max fit 16 bits (thresh255 <= 255 after the clamp below, which does
+// not change the outcome: for thresh255 >= 255 no pixel is ever skipped); the masked channel sums are
+// one v_dot2_u32_u16 per channel with the 0/1 keep flags as weights.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ void grayworld_add_swar(const Planar& v, unsigned thresh255, StatAcc& a) {
+  constexpr uint32_t M8 = 0x00FF00FFu;
+  const u16x2 t2 = as_u16x2(thresh255 * 0x00010001u), one2 = as_u16x2(0x00010001u);
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const uint32_t bw = (half ? v.b >> 8 : v.b) & M8, gw = (half ? v.g >> 8 : v.g) & M8, rw = (half ? v.r >> 8 : v.r) & M8;
+    const u16x2 b2 = as_u16x2(bw), g2 = as_u16x2(gw), r2 = as_u16x2(rw);
+    const u16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(b2, g2), r2);
+    const u16x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(b2, g2), r2);
+    const uint32_t d = __builtin_bit_cast(uint32_t, mx) - __builtin_bit_cast(uint32_t, mn);  // lane-wise: max >= min
+    const u16x2 lhs = as_u16x2((d << 8) - d);                                                // * 255, <= 65025 per lane
+    const u16x2 rhs = mx * t2;
+    const u16x2 skip = __builtin_elementwise_min(__builtin_elementwise_sub_sat(lhs, rhs), one2);  // 1 where lhs > rhs
+    const u16x2 keep = one2 - skip;
+    a.s[0] = __builtin_amdgcn_udot2(b2, keep, a.s[0], false);
+    a.s[1] = __builtin_amdgcn_udot2(g2, keep, a.s[1], false);
+    a.s[2] = __builtin_amdgcn_udot2(r2, keep, a.s[2], false);
+  }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, ItemMap im, int items_per_frame) {
-  __shared__ unsigned s_hist[768];
+  __shared__ unsigned s_hist[MODE == WB_SIMPLE ? 768 : 1];
+  p.mode = MODE;  // the per-pixel switch in stat_add folds away
   stat_hist_init(p, s_hist);
   const int frame = blockIdx.y;
-  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
+  const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
+  const unsigned thresh255 = min(p.thresh255, 255u);
   StatAcc a = {};
   for (int item = blockIdx.x * kBlock + threadIdx.x; item < items_per_frame; item += gridDim.x * kBlock) {
     int pair, grp;
     im.split(item, pair, grp);
     const int y0 = pair * 2, x0 = grp * 4;
     Window win;
-    load_window(src, (unsigned)p.src_step, p.rows, p.cols, y0, x0, win);
+    load_window(src, window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0), win);
     Planar rowpx[2];
     debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
 #pragma unroll
-    for (int ly = 0; ly < 2; ly++)
+    for (int ly = 0; ly < 2; ly++) {
+      if (MODE == WB_Q8) {
+        grayworld_add_swar(rowpx[ly], thresh255, a);
+        continue;
+      }
 #pragma unroll
       for (int lx = 0; lx < 4; lx++)
         stat_add(p, (int)((rowpx[ly].b >> (8 * lx)) & 0xFFu), (int)((rowpx[ly].g >> (8 * lx)) & 0xFFu),
                  (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a, s_hist);
+    }
   }
   stat_flush(p, a, p.stats + frame, s_hist, frame);
 }
@@ -1460,16 +1554,17 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
         const unsigned fy = w >> 27, wy0 = 32u - fy, wy1 = fy;
         const unsigned wB = wxb[k], wx0 = wB & 0xffu, wx1 = wB >> 24;
         const unsigned wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
-        const unsigned topB = __builtin_amdgcn_udot4(t0, wB, 0u, false);
-        const unsigned topG = __builtin_amdgcn_udot4(t0, wG0, __builtin_amdgcn_udot4(t1, wx1, 0u, false), false);
-        const unsigned topR = __builtin_amdgcn_udot4(t0, wR0, __builtin_amdgcn_udot4(t1, wR1, 0u, false), false);
-        const unsigned botB = __builtin_amdgcn_udot4(b0, wB, 0u, false);
-        const unsigned botG = __builtin_amdgcn_udot4(b0, wG0, __builtin_amdgcn_udot4(b1, wx1, 0u, false), false);
-        const unsigned botR = __builtin_amdgcn_udot4(b0, wR0, __builtin_amdgcn_udot4(b1, wR1, 0u, false), false);
+        // every row sum starts at 16: 16 * (32 - fy) + 16 * fy = 512 is the rounding term of
         // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15, exact
-        q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1) + 512u) >> 10);
-        q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1) + 512u) >> 10);
-        q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1) + 512u) >> 10);
+        const unsigned topB = __builtin_amdgcn_udot4(t0, wB, 16u, false);
+        const unsigned topG = __builtin_amdgcn_udot4(t0, wG0, __builtin_amdgcn_udot4(t1, wx1, 16u, false), false);
+        const unsigned topR = __builtin_amdgcn_udot4(t0, wR0, __builtin_amdgcn_udot4(t1, wR1, 16u, false), false);
+        const unsigned botB = __builtin_amdgcn_udot4(b0, wB, 16u, false);
+        const unsigned botG = __builtin_amdgcn_udot4(b0, wG0, __builtin_amdgcn_udot4(b1, wx1, 16u, false), false);
+        const unsigned botR = __builtin_amdgcn_udot4(b0, wR0, __builtin_amdgcn_udot4(b1, wR1, 16u, false), false);
+        q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1)) >> 10);
+        q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1)) >> 10);
+        q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1)) >> 10);
       }
       uint8_t* dst = b.dst + (size_t)f * b.dst_frame_stride;
       store12(dst + dst_off, pack4(q));
@@ -1528,6 +1623,153 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
         __syncthreads();
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring version of the tiled remap: the source rectangle of frame f+D is copied global -> LDS by the
+// LDS-DMA path (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass) while frame f is
+// gathered, D = stages - 1 frames ahead, so the HBM/TLB latency of the 15 MB frame-to-frame stride is
+// covered by D gathers instead of one.  hipcc drains vmcnt to 0 at every barrier when it knows about
+// an LDS-DMA in flight, so the loads are inline asm and counted here: every wave issues exactly PRE
+// loads per frame (lanes past the rectangle load from an out-of-range offset, which the buffer
+// resource turns into zeros), loads of one wave land in order, and "loads of frame f have landed" is
+// s_waitcnt vmcnt((frames issued after f) * PRE) -- stores in flight only make that wait longer.
+// One barrier per frame: after it every wave's part of frame f is in LDS and every wave is done
+// with frame f-1, whose stage is the one refilled next.
+// The staged image is chunk-linear (chunk i of the rectangle at byte 16*i: the row pitch is a whole
+// number of chunks), which is exactly the order LDS-DMA writes (M0 base + lane * 16).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voffset), "s"(rsrc), "s"(lds_wave_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+template <int PRE>
+__global__ __launch_bounds__(kBlock) void remap_ring_kernel(RemapTiledParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr unsigned kStage = (unsigned)PRE * kBlock * 16u;  // bytes per stage
+  const RemapParams& b = p.base;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 4, lgrp = tid & 15;
+  const unsigned step = (unsigned)b.src_step;
+  const int f_per_group = (b.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(b.n_frames, f_begin + f_per_group);
+  if (f_begin >= f_end) return;  // uniform for the workgroup
+  const int nb = p.stages, dist = nb - 1;  // ring size, prefetch distance (2 or 3)
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);
+  const unsigned wave_chunk0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);
+  const unsigned dst_bytes = __umul24((unsigned)(b.drows - 1), (unsigned)b.dst_step) + (unsigned)b.dcols * 3u;
+  for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
+    const int tile = xcd * per_xcd + ti;
+    if (tile >= ntiles) break;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const RemapTileDesc d = p.tiles[tile];
+    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * 1024)[tid];
+    const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
+    const int yd = ty * 16 + lrow, xd = tx * 64 + lgrp * 4;
+    const bool in_image = yd < b.drows && xd < b.dcols;
+    const unsigned xbyte0 = (unsigned)d.x0 * 3u;
+    const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
+    const unsigned pitch = ((unsigned)d.w * 3u + 15u + 12u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
+    const unsigned chunks = pitch >> 4;
+    const unsigned total = d.w > 0 ? chunks * (unsigned)d.h : 0u;
+    const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
+    // frame-invariant: source offsets of this lane's chunks, LDS address of the top-left tap, weights.
+    // Outside / border pixels gather address 0 with zero weights: 16 * 32 >> 10 == 0 is the border
+    // constant, and remap_border_kernel patches the border pixels afterwards -- no branch per pixel.
+    unsigned goff[PRE];
+#pragma unroll
+    for (int j = 0; j < PRE; j++) {
+      const unsigned i = (unsigned)tid + (unsigned)j * kBlock;
+      int r, c;
+      cm.split((int)i, r, c);
+      goff[j] = i < total ? __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFF0u;
+    }
+    unsigned tap_addr[4], wxb[4], wyy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t w = words[k];
+      const bool live = w < kPlanBorder;
+      const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u, fy = w >> 27;
+      tap_addr[k] = live ? __umul24(rely, pitch) + relx * 3u + ph : 0u;
+      wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
+      wyy[k] = (32u - fy) | (fy << 16);
+    }
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u;
+
+    auto issue = [&](int f, int slot) {
+      const RemapSrc s = remap_src(b, f);
+      const __amdgpu_buffer_rsrc_t rsrc = frame_rsrc(s.frame, s.readable);
+      const unsigned stage = lds0 + (unsigned)slot * kStage;
+#pragma unroll
+      for (int j = 0; j < PRE; j++) lds_dma16(rsrc, goff[j], stage + ((wave_chunk0 + (unsigned)j * kBlock) << 4));
+    };
+    auto gather_store = [&](const uint8_t* buf, int f) {
+      if (!in_image) return;
+      uint32_t t0[4], t1[4], b0[4], b1[4];  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        lds_load6(buf, tap_addr[k], t0[k], t1[k]);
+        lds_load6(buf, tap_addr[k] + pitch, b0[k], b1[k]);
+      }
+      int q[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned wy0 = wyy[k] & 0xffffu, wy1 = wyy[k] >> 16;
+        const unsigned wB = wxb[k], wx0 = wB & 0xffu, wx1 = wB >> 24;
+        const unsigned wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
+        // every row sum starts at 16: 16 * (32 - fy) + 16 * fy = 512 is the rounding term of
+        // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15, exact
+        const unsigned topB = __builtin_amdgcn_udot4(t0[k], wB, 16u, false);
+        const unsigned topG = __builtin_amdgcn_udot4(t0[k], wG0, __builtin_amdgcn_udot4(t1[k], wx1, 16u, false), false);
+        const unsigned topR = __builtin_amdgcn_udot4(t0[k], wR0, __builtin_amdgcn_udot4(t1[k], wR1, 16u, false), false);
+        const unsigned botB = __builtin_amdgcn_udot4(b0[k], wB, 16u, false);
+        const unsigned botG = __builtin_amdgcn_udot4(b0[k], wG0, __builtin_amdgcn_udot4(b1[k], wx1, 16u, false), false);
+        const unsigned botR = __builtin_amdgcn_udot4(b0[k], wR0, __builtin_amdgcn_udot4(b1[k], wR1, 16u, false), false);
+        q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1)) >> 10);
+        q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1)) >> 10);
+        q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1)) >> 10);
+      }
+      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, pack4(q));
+    };
+
+    // every earlier memory operation of this wave (plan words, tile descriptor, previous stores) is
+    // waited for here, so the counted waits below see only this tile's ring loads and stores
+    wait_vmcnt<0>();
+    int slot_in = 0, slot_out = 0;  // ring positions of the next frame to issue / to gather
+    for (int f = f_begin; f < f_end && f < f_begin + dist; f++) {
+      issue(f, slot_in);
+      slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
+    }
+    for (int f = f_begin; f < f_end; f++) {
+      const int ahead = min(dist - 1, f_end - 1 - f);  // frames issued after f and still allowed in flight
+      if (ahead >= 2)
+        wait_vmcnt<2 * PRE>();
+      else if (ahead == 1)
+        wait_vmcnt<PRE>();
+      else
+        wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (f + dist < f_end) {
+        issue(f + dist, slot_in);
+        slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
+      }
+      gather_store(lds + (unsigned)slot_out * kStage, f);
+      slot_out = slot_out + 1 == nb ? 0 : slot_out + 1;
+    }
+    __builtin_amdgcn_s_barrier();  // the next tile's prologue refills stages other waves may still be reading
   }
 }
 
@@ -1652,7 +1894,13 @@ void launch_stats(const StatsParams& p, hipStream_t stream) {
     // keep >= 1 block per 2^20 items so the 32-bit per-thread partial sums cannot overflow
     int per_frame = grid_blocks_for(items, std::max(8, tune_env("RIP_STATS_BLOCKS", 2048) / std::max(1, std::min(p.n_frames, 16))));
     per_frame = std::max(per_frame, (int)((items + (1 << 20) - 1) >> 20));
-    hipLaunchKernelGGL(stats_fast_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
+    const dim3 grid(per_frame, p.n_frames);
+    if (p.mode == WB_Q8)
+      hipLaunchKernelGGL(stats_fast_kernel<WB_Q8>, grid, dim3(kBlock), 0, stream, p, im, items);
+    else if (p.mode == WB_SIMPLE)
+      hipLaunchKernelGGL(stats_fast_kernel<WB_SIMPLE>, grid, dim3(kBlock), 0, stream, p, im, items);
+    else
+      hipLaunchKernelGGL(stats_fast_kernel<WB_PCA>, grid, dim3(kBlock), 0, stream, p, im, items);
     return;
   }
   if (color_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind)) {
@@ -1705,21 +1953,42 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
   RemapTiledParams q = p;
   q.lds_bytes = (std::max(p.lds_bytes, 16u) + 15u) & ~15u;
   const unsigned chunks = q.lds_bytes / 16u;  // upper bound of the 16-byte chunks of any tile
-  int pre = b.n_frames < 2 ? 0 : (chunks <= 2u * kBlock ? 2 : (chunks <= 4u * kBlock ? 4 : 0));
-  if (const char* e = std::getenv("RIP_REMAP_PRE")) pre = std::min(pre, std::atoi(e));
-  q.double_buffer = pre > 0 ? 1 : 0;
-  const unsigned lds = q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes;
-  const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
-  int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
-  blocks = std::max(8, blocks / 8 * 8);
-  const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too
-  const dim3 grid(blocks, groups);
-  if (pre == 2)
-    hipLaunchKernelGGL(remap_tiled_kernel<2>, grid, dim3(kBlock), lds, stream, q);
-  else if (pre == 4)
-    hipLaunchKernelGGL(remap_tiled_kernel<4>, grid, dim3(kBlock), lds, stream, q);
-  else
-    hipLaunchKernelGGL(remap_tiled_kernel<0>, grid, dim3(kBlock), lds, stream, q);
+  const int ring_env = std::getenv("RIP_REMAP_RING") ? std::atoi(std::getenv("RIP_REMAP_RING")) : 1;
+  // 2 stages (one frame ahead) measured best: the kernel moves ~2.6 GB per 64-frame launch at ~4.3 TB/s, so
+  // residency (7 workgroups per CU at 16 KiB) is worth more than a deeper ring
+  const int stages_env = tune_env("RIP_REMAP_STAGES", 2);
+  if (ring_env && chunks <= 4u * kBlock) {
+    // LDS-DMA ring: PRE chunks per lane and frame, `stages` buffers of PRE * 4 KiB
+    const int pre = chunks <= 1u * kBlock ? 1 : (chunks <= 2u * kBlock ? 2 : 4);
+    const unsigned stage_bytes = (unsigned)pre * kBlock * 16u;
+    q.stages = std::max(2, std::min(4, stages_env));
+    const unsigned lds = (unsigned)q.stages * stage_bytes;
+    const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
+    int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
+    blocks = std::max(8, blocks / 8 * 8);
+    const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too
+    const dim3 grid(blocks, groups);
+    if (pre == 1)
+      hipLaunchKernelGGL(remap_ring_kernel<1>, grid, dim3(kBlock), lds, stream, q);
+    else if (pre == 2)
+      hipLaunchKernelGGL(remap_ring_kernel<2>, grid, dim3(kBlock), lds, stream, q);
+    else
+      hipLaunchKernelGGL(remap_ring_kernel<4>, grid, dim3(kBlock), lds, stream, q);
+  } else {
+    // rectangles larger than 4 * kBlock chunks (strong local magnification) or RIP_REMAP_RING=0 (A/B runs)
+    int pre = !ring_env && b.n_frames >= 2 && chunks <= 2u * kBlock ? 2 : 0;
+    q.double_buffer = pre > 0 ? 1 : 0;
+    const unsigned lds = q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes;
+    const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
+    int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
+    blocks = std::max(8, blocks / 8 * 8);
+    const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too
+    const dim3 grid(blocks, groups);
+    if (pre == 2)
+      hipLaunchKernelGGL(remap_tiled_kernel<2>, grid, dim3(kBlock), lds, stream, q);
+    else
+      hipLaunchKernelGGL(remap_tiled_kernel<0>, grid, dim3(kBlock), lds, stream, q);
+  }
   if (q.n_border > 0)
     hipLaunchKernelGGL(remap_border_kernel, dim3((q.n_border + kBlock - 1) / kBlock, b.n_frames), dim3(kBlock), 0, stream, q);
   return true;

@@ -152,6 +152,7 @@ struct RemapTiledParams {
   int n_border;
   unsigned lds_bytes;          // dynamic LDS per staging buffer (>= max over tiles)
   int double_buffer;           // set by the launcher: two staging buffers, loads of frame f+1 overlap the gather of f
+  int stages;                  // set by the launcher (ring kernel): LDS ring size, prefetch distance = stages - 1
 };
 
 // ---- launchers (asynchronous on `stream`) -------------------------------------------------------

@@ -372,3 +372,27 @@ def test_pipeline_reference_schedule_gives_same_pixels(oracle):
     prm.reference_schedule = 1
     b, _ = oracle.pipeline(prm, frame, "bayer_grbg8")
     assert np.array_equal(a, b)
+
+
+def test_lab_ab_never_saturate(oracle):
+    """RGB2Lab_b saturates a and b to [0, 255]; over all 2^24 BGR inputs the unsaturated values stay inside
+    [42, 226] and [20, 223], so the device kernel drops the clamp (rip_kernels.hip apply_vignette) and folds
+    the float-to-int bias into the next multiply-add.  L covers exactly [0, 255]."""
+    g = oracle.table("srgb_gamma").astype(np.int64)
+    cb = oracle.table("cbrt").astype(np.int64)
+    C = oracle.table("fwd_coeffs").astype(np.int64)
+    lo = np.array([1 << 30] * 3)
+    hi = -lo
+    v1, v2 = g[:, None], g[None, :]
+    for v0 in g:
+        fX = cb[(v0 * C[0] + v1 * C[1] + v2 * C[2] + 2048) >> 12]
+        fY = cb[(v0 * C[3] + v1 * C[4] + v2 * C[5] + 2048) >> 12]
+        fZ = cb[(v0 * C[6] + v1 * C[7] + v2 * C[8] + 2048) >> 12]
+        L = (296 * fY - 1336935 + 16384) >> 15
+        a = (500 * (fX - fY) + 128 * 32768 + 16384) >> 15
+        b = (200 * (fY - fZ) + 128 * 32768 + 16384) >> 15
+        lo = np.minimum(lo, [L.min(), a.min(), b.min()])
+        hi = np.maximum(hi, [L.max(), a.max(), b.max()])
+    assert (lo[0], hi[0]) == (0, 255)
+    assert 0 < lo[1] and hi[1] < 255 and (lo[1], hi[1]) == (42, 226)
+    assert 0 < lo[2] and hi[2] < 255 and (lo[2], hi[2]) == (20, 223)

@@ -159,6 +159,26 @@ def test_undistortion_mono_and_map_size_differs_from_image(gpu_pipe, oracle):
     assert got.shape == (48, 64)
 
 
+@pytest.mark.parametrize("fov,stages,ring", [(0.6, 2, 1), (0.6, 4, 1), (1.0, 2, 1), (1.0, 3, 1), (1.0, 4, 1), (2.0, 2, 1),
+                                               (2.0, 3, 1), (3.6, 2, 1), (1.0, 2, 0), (2.0, 2, 0)])
+def test_undistortion_batch_through_the_lds_ring(gpu_pipe, oracle, monkeypatch, fov, stages, ring):
+    """The tiled remap streams the frames of a batch through an LDS ring (LDS-DMA, `stages` buffers).  fov_scale
+    widens the source rectangle of a tile: 1 chunk per lane (0.6), 2 (1.0), 4 (2.0), then the unpipelined fallback kernel (3.6)."""
+    import torch
+    monkeypatch.setenv("RIP_REMAP_STAGES", str(stages))
+    monkeypatch.setenv("RIP_REMAP_RING", str(ring))
+    w, h, n = 448, 272, 7
+    c = cfg(undistort=True, cam=synth.camera_model(w, h), fov_scale=fov)
+    configure(gpu_pipe, c)
+    frames = np.stack([synth.gen_frame(w, h, "bayer_grbg8", seed=300 + i, kind="uniform") for i in range(n)])
+    out = gpu_pipe.apply_device(torch.from_numpy(frames).cuda(), "bayer_grbg8")
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i in range(n):
+        ref, _ = oracle_run(oracle, c, frames[i], "bayer_grbg8")
+        assert_images_equal(out[i], ref, "ring frame %d (fov %g, %d stages)" % (i, fov, stages))
+
+
 def full_chain_cfg(w, h, **kw):
     base = dict(flip=True, flip_angle=180, wb=True, wb_method="grey_world", cc=True, gamma=True, gamma_k=0.8, vig=True,
                 undistort=True, cam=synth.camera_model(w, h))
