@@ -252,6 +252,12 @@ void ensure_tables(rip_pipeline* p) {
   std::memcpy(t.hdiv, c.hdiv180, sizeof(t.hdiv));
   std::memcpy(t.lab_fwd, c.fwd, sizeof(t.lab_fwd));
   std::memcpy(t.lab_inv, c.inv, sizeof(t.lab_inv));
+  for (int ch = 0; ch < 3; ch++) {
+    if (c.inv[ch * 3] < -32768 || c.inv[ch * 3] > 32767 || c.inv[ch * 3 + 1] < -32768 || c.inv[ch * 3 + 1] > 32767)
+      throw std::runtime_error("Lab inverse coefficients do not fit 16 bits");
+    t.lab_inv_pk[ch * 2] = (int32_t)(((uint32_t)c.inv[ch * 3] & 0xffffu) | ((uint32_t)c.inv[ch * 3 + 1] << 16));
+    t.lab_inv_pk[ch * 2 + 1] = c.inv[ch * 3 + 2];
+  }
   std::vector<float> accum;
   rip::ccc_build_scalar_tables(t.log_tab, accum, t.exp_neg_tab);
   rip::fft256_twiddles(t.tw_re, t.tw_im);

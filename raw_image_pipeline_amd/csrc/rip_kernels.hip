@@ -291,6 +291,7 @@ __device__ __forceinline__ void ab_to_xz_pair(int ix, int iz, int& x, int& z) {
 // below 2^23, so the products and sums are exact.  floor(T / 2^n) of an integer T is taken as
 // RN((T + 0.5) / 2^n - 0.5) -- never a tie -- by adding the magic constant 1.5 * 2^23 inside the
 // FMA, which leaves the integer in the low mantissa bits.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
 template <typename Tabs>
 __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs& tb, const float* fwd, const int* inv,
                                                float mask, int& b, int& g, int& r) {
@@ -326,9 +327,13 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
   const int bdiv = (int)((__umul24(bbits, kB) + ((1u << 4) - 0x400000u * kB)) >> 9) - 128 * 16384 / 200 + 1;
   int x, z;
   ab_to_xz_pair(ify + adiv, ify - bdiv, x, z);
-  const int bo = mad24(inv[2], z, mad24(inv[1], y, mad24(inv[0], x, 1 << 13))) >> 14;
-  const int go = mad24(inv[5], z, mad24(inv[4], y, mad24(inv[3], x, 1 << 13))) >> 14;
-  const int ro = mad24(inv[8], z, mad24(inv[7], y, mad24(inv[6], x, 1 << 13))) >> 14;
+  // x in [-652, 28028] (a in [42, 226], L <= 255) and y in [0, 16384] fit 16 bits, the coefficients too: the
+  // x and y terms of a row are one v_dot2_i32_i16; z reaches 59.9k and stays on the 24-bit multiply-add.
+  // No intermediate leaves 31 bits.  inv = DevTables::lab_inv_pk.
+  const i16x2 xy = {(short)x, (short)y};
+  const int bo = __builtin_amdgcn_sdot2(xy, __builtin_bit_cast(i16x2, inv[0]), mad24(inv[1], z, 1 << 13), false) >> 14;
+  const int go = __builtin_amdgcn_sdot2(xy, __builtin_bit_cast(i16x2, inv[2]), mad24(inv[3], z, 1 << 13), false) >> 14;
+  const int ro = __builtin_amdgcn_sdot2(xy, __builtin_bit_cast(i16x2, inv[4]), mad24(inv[5], z, 1 << 13), false) >> 14;
   b = tb.invg(clampi(bo, 0, 4095));
   g = tb.invg(clampi(go, 0, 4095));
   r = tb.invg(clampi(ro, 0, 4095));
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
       t[1] = (uint8_t)g;
       t[2] = (uint8_t)r;
     }
-    pointwise<-1, -1>(p, w, tb, fwdf, p.tabs->lab_inv, (p.stage_bits & ST_VIG) ? vignette_mask(p, yd, xd) : 1.0f, b, g, r);
+    pointwise<-1, -1>(p, w, tb, fwdf, p.tabs->lab_inv_pk, (p.stage_bits & ST_VIG) ? vignette_mask(p, yd, xd) : 1.0f, b, g, r);
     uint8_t* o = dst + (size_t)yd * p.dst_step + (size_t)xd * 3;
     o[0] = (uint8_t)b;
     o[1] = (uint8_t)g;
@@ -506,55 +511,75 @@ __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b)
 // split into its even and odd bytes, widened to 16-bit lanes inside a dword, so one v_add_u32 adds
 // two taps of two pixels and the sums (<= 4*255 + 2) cannot carry across lanes.
 // RY/RX: position of the R sample in the 2x2 cell.  out[ly] = image row y0 + ly.
-template <int RY, int RX>
-__device__ __forceinline__ void debayer_swar(const Window& win, Planar (&out)[2]) {
+// One window row prepared for the SWAR sums: the centre dword, the two shifted views and their
+// even / odd bytes widened to 16-bit lanes.
+struct RowPrep {
+  uint32_t c, wm, wp;        // columns x0 .. x0+3, x0-1 .. x0+2, x0+1 .. x0+4
+  uint32_t hs_lo, hs_hi;     // left + right neighbour of pixels (0, 2) and (1, 3)
+  uint32_t c_lo, c_hi;       // centre bytes of pixels (0, 2) and (1, 3)
+};
+__device__ __forceinline__ RowPrep prep_row(uint32_t left, uint32_t centre, uint32_t right) {
   constexpr uint32_t M8 = 0x00FF00FFu;
-  uint32_t hs_lo[4], hs_hi[4], c_lo[4], c_hi[4], wm[4], wp[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    wm[r] = __builtin_amdgcn_alignbyte(win.w[r][1], win.w[r][0], 3);  // columns x0-1 .. x0+2
-    wp[r] = __builtin_amdgcn_alignbyte(win.w[r][2], win.w[r][1], 1);  // columns x0+1 .. x0+4
-    hs_lo[r] = (wm[r] & M8) + (wp[r] & M8);  // left + right neighbour, pixels 0 and 2
-    hs_hi[r] = ((wm[r] >> 8) & M8) + ((wp[r] >> 8) & M8);  // pixels 1 and 3
-    c_lo[r] = win.w[r][1] & M8;
-    c_hi[r] = (win.w[r][1] >> 8) & M8;
-  }
-  constexpr uint32_t kEven = RX == 0 ? 0x00FF00FFu : 0xFF00FF00u;  // byte lanes with dx == 0
-#pragma unroll
-  for (int ly = 0; ly < 2; ly++) {
-    const int cr = ly + 1;
-    // two-tap averages (a + b + 1) >> 1 of all four byte lanes in one v_lerp_u8
-    const uint32_t H = __builtin_amdgcn_lerp(wm[cr], wp[cr], 0x01010101u);
-    const uint32_t V = __builtin_amdgcn_lerp(win.w[cr - 1][1], win.w[cr + 1][1], 0x01010101u);
-    const uint32_t X4 = (((hs_lo[cr] + c_lo[cr - 1] + c_lo[cr + 1] + 0x00020002u) >> 2) & M8) |
-                        ((((hs_hi[cr] + c_hi[cr - 1] + c_hi[cr + 1] + 0x00020002u) >> 2) & M8) << 8);
-    const uint32_t D4 = (((hs_lo[cr - 1] + hs_lo[cr + 1] + 0x00020002u) >> 2) & M8) |
-                        ((((hs_hi[cr - 1] + hs_hi[cr + 1] + 0x00020002u) >> 2) & M8) << 8);
-    const uint32_t C = win.w[cr][1];
-    if (((ly ^ RY) & 1) == 0) {
-      // red row: dx == 0 -> R site (B = diag, G = cross, R = centre); dx == 1 -> G site (B = vert, R = horiz)
-      out[ly].b = bfi32(kEven, D4, V);
-      out[ly].g = bfi32(kEven, X4, C);
-      out[ly].r = bfi32(kEven, C, H);
-    } else {
-      // blue row: dx == 0 -> G site (B = horiz, R = vert); dx == 1 -> B site (B = centre, G = cross, R = diag)
-      out[ly].b = bfi32(kEven, H, C);
-      out[ly].g = bfi32(kEven, C, X4);
-      out[ly].r = bfi32(kEven, V, D4);
-    }
-  }
+  RowPrep r;
+  r.c = centre;
+  r.wm = __builtin_amdgcn_alignbyte(centre, left, 3);
+  r.wp = __builtin_amdgcn_alignbyte(right, centre, 1);
+  r.hs_lo = (r.wm & M8) + (r.wp & M8);
+  r.hs_hi = ((r.wm >> 8) & M8) + ((r.wp >> 8) & M8);
+  r.c_lo = centre & M8;
+  r.c_hi = (centre >> 8) & M8;
+  return r;
 }
 
-// demosaic of the 4x2 tile at (y0, x0) including OpenCV's border replication (column 0 := column 1,
-// column W-1 := W-2, then row 0 := row 1, row H-1 := H-2)
-__device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int rx, int y0, int x0, int rows, int cols,
-                                                 Planar (&out)[2]) {
-  switch (ry * 2 + rx) {
-    case 0: debayer_swar<0, 0>(win, out); break;
-    case 1: debayer_swar<0, 1>(win, out); break;
-    case 2: debayer_swar<1, 0>(win, out); break;
-    default: debayer_swar<1, 1>(win, out); break;
+// One output row (four pixels) from the prepared rows above / at / below it.
+// RED_ROW: the row holds R samples; RX: column parity of the R samples.
+template <bool RED_ROW, int RX>
+__device__ __forceinline__ Planar debayer_row(const RowPrep& up, const RowPrep& at, const RowPrep& dn) {
+  constexpr uint32_t M8 = 0x00FF00FFu;
+  constexpr uint32_t kEven = RX == 0 ? 0x00FF00FFu : 0xFF00FF00u;  // byte lanes with dx == 0
+  // two-tap averages (a + b + 1) >> 1 of all four byte lanes in one v_lerp_u8
+  const uint32_t H = __builtin_amdgcn_lerp(at.wm, at.wp, 0x01010101u);
+  const uint32_t V = __builtin_amdgcn_lerp(up.c, dn.c, 0x01010101u);
+  const uint32_t X4 = (((at.hs_lo + up.c_lo + dn.c_lo + 0x00020002u) >> 2) & M8) |
+                      ((((at.hs_hi + up.c_hi + dn.c_hi + 0x00020002u) >> 2) & M8) << 8);
+  const uint32_t D4 = (((up.hs_lo + dn.hs_lo + 0x00020002u) >> 2) & M8) | ((((up.hs_hi + dn.hs_hi + 0x00020002u) >> 2) & M8) << 8);
+  const uint32_t C = at.c;
+  Planar o;
+  if (RED_ROW) {
+    // red row: dx == 0 -> R site (B = diag, G = cross, R = centre); dx == 1 -> G site (B = vert, R = horiz)
+    o.b = bfi32(kEven, D4, V);
+    o.g = bfi32(kEven, X4, C);
+    o.r = bfi32(kEven, C, H);
+  } else {
+    // blue row: dx == 0 -> G site (B = horiz, R = vert); dx == 1 -> B site (B = centre, G = cross, R = diag)
+    o.b = bfi32(kEven, H, C);
+    o.g = bfi32(kEven, C, X4);
+    o.r = bfi32(kEven, V, D4);
   }
+  return o;
+}
+
+// Bilinear demosaic of the 4x2 tile, four pixels per instruction (SWAR): every row of the window is
+// split into its even and odd bytes, widened to 16-bit lanes inside a dword, so one v_add_u32 adds
+// two taps of two pixels and the sums (<= 4*255 + 2) cannot carry across lanes.
+// RY/RX: position of the R sample in the 2x2 cell.  out[ly] = image row y0 + ly; r[k] = row y0 - 1 + k.
+template <int RY, int RX>
+__device__ __forceinline__ void debayer_rows(const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3,
+                                             Planar (&out)[2]) {
+  out[0] = debayer_row<RY == 0, RX>(r0, r1, r2);
+  out[1] = debayer_row<RY == 1, RX>(r1, r2, r3);
+}
+template <int RY, int RX>
+__device__ __forceinline__ void debayer_swar(const Window& win, Planar (&out)[2]) {
+  RowPrep r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) r[k] = prep_row(win.w[k][0], win.w[k][1], win.w[k][2]);
+  debayer_rows<RY, RX>(r[0], r[1], r[2], r[3], out);
+}
+
+// OpenCV's border replication on a demosaiced 4x2 tile: column 0 := column 1, column W-1 := W-2,
+// then row 0 := row 1, row H-1 := H-2
+__device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int cols, Planar (&out)[2]) {
   if (x0 == 0) {
 #pragma unroll
     for (int ly = 0; ly < 2; ly++) {
@@ -573,6 +598,27 @@ __device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int 
   }
   if (y0 == 0) out[0] = out[1];
   if (y0 + 2 == rows) out[1] = out[0];
+}
+__device__ __forceinline__ void debayer_rows_any(const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3, int ry,
+                                                 int rx, Planar (&out)[2]) {
+  switch (ry * 2 + rx) {
+    case 0: debayer_rows<0, 0>(r0, r1, r2, r3, out); break;
+    case 1: debayer_rows<0, 1>(r0, r1, r2, r3, out); break;
+    case 2: debayer_rows<1, 0>(r0, r1, r2, r3, out); break;
+    default: debayer_rows<1, 1>(r0, r1, r2, r3, out); break;
+  }
+}
+
+// demosaic of the 4x2 tile at (y0, x0) including OpenCV's border replication
+__device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int rx, int y0, int x0, int rows, int cols,
+                                                 Planar (&out)[2]) {
+  switch (ry * 2 + rx) {
+    case 0: debayer_swar<0, 0>(win, out); break;
+    case 1: debayer_swar<0, 1>(win, out); break;
+    case 2: debayer_swar<1, 0>(win, out); break;
+    default: debayer_swar<1, 1>(win, out); break;
+  }
+  debayer_fix_edges(y0, x0, rows, cols, out);
 }
 
 // planar -> interleaved BGR (12 bytes) with six v_perm_b32
@@ -641,11 +687,11 @@ template <int BITS, int WB>
 __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
   __shared__ LdsTabs<BITS> tb;
   __shared__ float s_fwd[9];
-  __shared__ int s_inv[9];
+  __shared__ int s_inv[6];
   tb.load(p.tabs);
   if (threadIdx.x < 9) {
     s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
-    s_inv[threadIdx.x] = p.tabs->lab_inv[threadIdx.x];
+    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
   }
   __syncthreads();
   // Persistent workgroups: the LDS tables are loaded once and amortised over many chunks of
@@ -758,12 +804,12 @@ __global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, Item
   __shared__ LdsTabs<ST_CC | ST_GAMMA | ST_VIG | ST_HSV> tb;
   __shared__ uint8_t s_gamma[256];  // LdsTabs<...VIG> folds gamma into lin_tab; the plain LUT is needed too
   __shared__ float s_fwd[9];
-  __shared__ int s_inv[9];
+  __shared__ int s_inv[6];
   tb.load(p.tabs);
   s_gamma[threadIdx.x] = p.tabs->gamma_lut[threadIdx.x];
   if (threadIdx.x < 9) {
     s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
-    s_inv[threadIdx.x] = p.tabs->lab_inv[threadIdx.x];
+    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
   }
   __syncthreads();
   const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
@@ -927,34 +973,74 @@ __device__ __forceinline__ void grayworld_add_swar(const Planar& v, unsigned thr
   }
 }
 
+// Statistics of a Bayer frame.  A wave owns a strip 64 groups (256 px) wide and walks down
+// `pairs_per_task` row pairs of it: the row index is wave-uniform, so a row's byte offset lives in an
+// SGPR (the buffer instruction's soffset) and the three per-lane column offsets never change -- no
+// per-item address arithmetic -- and two of the four window rows (with their SWAR preparation) carry
+// over from one row pair to the next.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, ItemMap im, int items_per_frame) {
+__global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, int col_waves, int pairs_per_task, int n_tasks) {
   __shared__ unsigned s_hist[MODE == WB_SIMPLE ? 768 : 1];
   p.mode = MODE;  // the per-pixel switch in stat_add folds away
   stat_hist_init(p, s_hist);
   const int frame = blockIdx.y;
-  const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
+  const unsigned step = (unsigned)p.src_step;
+  const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), step) + (unsigned)p.cols;
   const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
   const unsigned thresh255 = min(p.thresh255, 255u);
+  const int lane = threadIdx.x & 63;
+  const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
   StatAcc a = {};
-  for (int item = blockIdx.x * kBlock + threadIdx.x; item < items_per_frame; item += gridDim.x * kBlock) {
-    int pair, grp;
-    im.split(item, pair, grp);
-    const int y0 = pair * 2, x0 = grp * 4;
-    Window win;
-    load_window(src, window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0), win);
-    Planar rowpx[2];
-    debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
+  if (task < n_tasks) {
+    const int cw = task % col_waves, range = task / col_waves;
+    const int grp = cw * 64 + lane;
+    const bool active = grp * 4 < p.cols;
+    const int x0 = active ? grp * 4 : 0;
+    const int off_c = x0, off_l = x0 >= 4 ? x0 - 4 : x0, off_r = x0 + 4 < p.cols ? x0 + 4 : x0;
+    const int n_pairs = p.rows >> 1;
+    const int pair_begin = range * pairs_per_task, pair_end = min(n_pairs, pair_begin + pairs_per_task);
+    struct RawRow {
+      uint32_t l, c, r;
+    };
+    auto fetch_row = [&](int y) {
+      const int row = (int)__umul24((unsigned)clampi(y, 0, p.rows - 1), step);  // wave-uniform: scalar
+      return RawRow{__builtin_amdgcn_raw_buffer_load_b32(src, off_l, row, 0), __builtin_amdgcn_raw_buffer_load_b32(src, off_c, row, 0),
+                    __builtin_amdgcn_raw_buffer_load_b32(src, off_r, row, 0)};
+    };
+    auto prep = [&](const RawRow& w) { return prep_row(w.l, w.c, w.r); };
+    auto consume = [&](const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3, int y0) {
+      Planar rowpx[2];
+      debayer_rows_any(r0, r1, r2, r3, p.bayer_ry, p.bayer_rx, rowpx);
+      debayer_fix_edges(y0, x0, p.rows, p.cols, rowpx);
+      if (!active) return;
 #pragma unroll
-    for (int ly = 0; ly < 2; ly++) {
-      if (MODE == WB_Q8) {
-        grayworld_add_swar(rowpx[ly], thresh255, a);
-        continue;
+      for (int ly = 0; ly < 2; ly++) {
+        if (MODE == WB_Q8) {
+          grayworld_add_swar(rowpx[ly], thresh255, a);
+          continue;
+        }
+#pragma unroll
+        for (int lx = 0; lx < 4; lx++)
+          stat_add(p, (int)((rowpx[ly].b >> (8 * lx)) & 0xFFu), (int)((rowpx[ly].g >> (8 * lx)) & 0xFFu),
+                   (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a, s_hist);
       }
-#pragma unroll
-      for (int lx = 0; lx < 4; lx++)
-        stat_add(p, (int)((rowpx[ly].b >> (8 * lx)) & 0xFFu), (int)((rowpx[ly].g >> (8 * lx)) & 0xFFu),
-                 (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a, s_hist);
+    };
+    // two row pairs per iteration so the carried rows change roles without register moves; the two
+    // rows of the next pair are in flight while the current pair is reduced
+    int y0 = pair_begin * 2;
+    RowPrep ra = prep(fetch_row(y0 - 1)), rb = prep(fetch_row(y0));
+    RawRow n0 = fetch_row(y0 + 1), n1 = fetch_row(y0 + 2);
+    for (int pair = pair_begin; pair < pair_end; pair += 2, y0 += 4) {
+      const RowPrep rc = prep(n0), rd = prep(n1);
+      n0 = fetch_row(y0 + 3);
+      n1 = fetch_row(y0 + 4);
+      consume(ra, rb, rc, rd, y0);
+      if (pair + 1 >= pair_end) break;
+      ra = prep(n0);
+      rb = prep(n1);
+      n0 = fetch_row(y0 + 5);
+      n1 = fetch_row(y0 + 6);
+      consume(rc, rd, ra, rb, y0 + 2);
     }
   }
   stat_flush(p, a, p.stats + frame, s_hist, frame);
@@ -1892,15 +1978,23 @@ void launch_stats(const StatsParams& p, hipStream_t stream) {
     ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
     const int items = (p.rows / 2) * (p.cols / 4);
     // keep >= 1 block per 2^20 items so the 32-bit per-thread partial sums cannot overflow
-    int per_frame = grid_blocks_for(items, std::max(8, tune_env("RIP_STATS_BLOCKS", 2048) / std::max(1, std::min(p.n_frames, 16))));
-    per_frame = std::max(per_frame, (int)((items + (1 << 20) - 1) >> 20));
-    const dim3 grid(per_frame, p.n_frames);
+    // wave tasks: 64 groups wide x pairs_per_task row pairs.  The wave total of the largest statistic
+    // (pca: sum of squares) is 64 lanes * 8 px * 255^2 * pairs_per_task: 128 pairs keep it below 2^32
+    const int groups = p.cols / 4, n_pairs = p.rows / 2;
+    const int col_waves = (groups + 63) / 64;
+    const int target_tasks = std::max(8, tune_env("RIP_STATS_BLOCKS", 2048) * 4 / std::max(1, std::min(p.n_frames, 16)));
+    int pairs_per_task = std::max(2, (int)(((long long)col_waves * n_pairs + target_tasks - 1) / target_tasks));
+    pairs_per_task = std::min((pairs_per_task + 1) & ~1, 128);  // even: the kernel consumes two pairs per iteration
+    const int n_tasks = col_waves * ((n_pairs + pairs_per_task - 1) / pairs_per_task);
+    const dim3 grid((n_tasks + kBlock / 64 - 1) / (kBlock / 64), p.n_frames);
+    (void)items;
+    (void)im;
     if (p.mode == WB_Q8)
-      hipLaunchKernelGGL(stats_fast_kernel<WB_Q8>, grid, dim3(kBlock), 0, stream, p, im, items);
+      hipLaunchKernelGGL(stats_fast_kernel<WB_Q8>, grid, dim3(kBlock), 0, stream, p, col_waves, pairs_per_task, n_tasks);
     else if (p.mode == WB_SIMPLE)
-      hipLaunchKernelGGL(stats_fast_kernel<WB_SIMPLE>, grid, dim3(kBlock), 0, stream, p, im, items);
+      hipLaunchKernelGGL(stats_fast_kernel<WB_SIMPLE>, grid, dim3(kBlock), 0, stream, p, col_waves, pairs_per_task, n_tasks);
     else
-      hipLaunchKernelGGL(stats_fast_kernel<WB_PCA>, grid, dim3(kBlock), 0, stream, p, im, items);
+      hipLaunchKernelGGL(stats_fast_kernel<WB_PCA>, grid, dim3(kBlock), 0, stream, p, col_waves, pairs_per_task, n_tasks);
     return;
   }
   if (color_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind)) {

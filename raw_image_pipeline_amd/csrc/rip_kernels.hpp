@@ -26,6 +26,7 @@ struct DevTables {
   int32_t hdiv[256];
   int32_t lab_fwd[9];
   int32_t lab_inv[9];
+  int32_t lab_inv_pk[6];  // per output channel: (c_x & 0xffff) | (c_y << 16), c_z -- operands of v_dot2_i32_i16
   // ccc estimator
   float log_tab[256];
   float exp_neg_tab[256];

@@ -396,3 +396,23 @@ def test_lab_ab_never_saturate(oracle):
     assert (lo[0], hi[0]) == (0, 255)
     assert 0 < lo[1] and hi[1] < 255 and (lo[1], hi[1]) == (42, 226)
     assert 0 < lo[2] and hi[2] < 255 and (lo[2], hi[2]) == (20, 223)
+
+
+def test_lab_inverse_x_and_y_fit_16_bits(oracle):
+    """Lab2RGBinteger: with a in [42, 226] (see above) and any L, x = abToXZ_b[ify + adiv] stays inside int16 and so
+    does y -- the device kernel feeds (x, y) to v_dot2_i32_i16; z (b in [20, 223]) does not fit and is not packed."""
+    yf = oracle.table("lab_to_yf").reshape(256, 2)
+    y, ify = yf[:, 0], yf[:, 1]
+    assert 0 <= y.min() and y.max() <= 16384 and ify.max() <= 16384
+    xs, zs = [], []
+    for a in (42, 226):
+        adiv = ((a * 5 * 53687 + 128) >> 13) - 128 * 16384 // 500
+        xs += [oracle.ab_to_xz(int(ify.min()) + adiv), oracle.ab_to_xz(int(ify.max()) + adiv)]
+    for b in (20, 223):
+        bdiv = ((b * 41943 + 16) >> 9) - 128 * 16384 // 200 + 1
+        zs += [oracle.ab_to_xz(int(ify.min()) - bdiv), oracle.ab_to_xz(int(ify.max()) - bdiv)]
+    assert -32768 <= min(xs) and max(xs) <= 32767, xs   # abToXZ_b is monotone: the extremes are at the corners
+    assert max(zs) > 32767                               # which is why z stays on the 24-bit multiply
+    c = oracle.table("inv_coeffs")
+    assert np.abs(c).max() <= 32767
+    assert 2 * 32767 * int(np.abs(c).max()) + 65536 * int(np.abs(c).max()) + 8192 < 2 ** 31
