@@ -36,8 +36,18 @@ BYTES_PER_PX = {
     "stats": 1.0,   # Bayer read (grey-world / pca pre-pass)
     "ccc": 0.0,     # reads 4 x 360 x 270 taps per frame: O(1) per frame
     "chain": 4.0,   # 1 B Bayer read + 3 B BGR write
-    "remap": 14.0,  # 8 B float2 map + 3 B gather + 3 B write
+    # SURVEY's ledger prices the remap at 14 B/px (8 B float2 map + 3 B gather + 3 B write) per frame.  The
+    # tiled kernel reads a compiled plan (4 B/px) once per LAUNCH instead of the map once per frame, so
+    # the compulsory traffic of one launch is 3 + 3 + 4 / frames B/px; the roofline uses that (smaller)
+    # figure -- pricing it at 14 would report more than the HBM peak.
+    "remap": None,
 }
+
+
+def bytes_per_px(kernel_class, frames_per_launch):
+    if kernel_class == "remap":
+        return 6.0 + 4.0 / max(frames_per_launch, 1)
+    return BYTES_PER_PX[kernel_class]
 
 
 def parse_args():
@@ -230,7 +240,8 @@ def main():
     px = width * height
     dom = max(prof, key=lambda k: prof[k][0])
     dom_ms, dom_n = prof[dom]
-    per_launch_bytes = BYTES_PER_PX[dom] * px * args.batch
+    out_px = orows * ocols if dom == "remap" else px
+    per_launch_bytes = bytes_per_px(dom, args.batch) * out_px * args.batch
     avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
     achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     traffic = None

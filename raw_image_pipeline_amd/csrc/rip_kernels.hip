@@ -2048,16 +2048,16 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
   q.lds_bytes = (std::max(p.lds_bytes, 16u) + 15u) & ~15u;
   const unsigned chunks = q.lds_bytes / 16u;  // upper bound of the 16-byte chunks of any tile
   const int ring_env = std::getenv("RIP_REMAP_RING") ? std::atoi(std::getenv("RIP_REMAP_RING")) : 1;
-  // 2 stages (one frame ahead) measured best: the kernel moves ~2.6 GB per 64-frame launch at ~4.3 TB/s, so
-  // residency (7 workgroups per CU at 16 KiB) is worth more than a deeper ring
-  const int stages_env = tune_env("RIP_REMAP_STAGES", 2);
+  // measured on config2 (sweeps in DESIGN.md): 3 stages (two frames ahead) with 4 workgroups per CU; more resident
+  // workgroups fetch more (the source rectangles of neighbouring tiles stop meeting in L2) and run slower
+  const int stages_env = tune_env("RIP_REMAP_STAGES", 3);
   if (ring_env && chunks <= 4u * kBlock) {
     // LDS-DMA ring: PRE chunks per lane and frame, `stages` buffers of PRE * 4 KiB
     const int pre = chunks <= 1u * kBlock ? 1 : (chunks <= 2u * kBlock ? 2 : 4);
     const unsigned stage_bytes = (unsigned)pre * kBlock * 16u;
     q.stages = std::max(2, std::min(4, stages_env));
     const unsigned lds = (unsigned)q.stages * stage_bytes;
-    const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
+    const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 4), (int)((160u * 1024u) / (lds + 256u))));
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
     blocks = std::max(8, blocks / 8 * 8);
     const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too

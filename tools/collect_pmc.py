@@ -56,7 +56,7 @@ def main():
             total = 0.0
             for short, d in sorted(kernels.items()):
                 fetch, write = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
-                factor = 2.0 if short == "remap_tiled_kernel" else 1.0
+                factor = 2.0 if short in ("remap_tiled_kernel", "remap_ring_kernel") else 1.0  # 16 B/lane loads: MI355X_MICROARCH.md, HBM section
                 fb, wb = med(fetch) * 1024 * factor, med(write) * 1024
                 total += fb + wb
                 lines.append("%-8s %-6s %-22s launches=%-3d FETCH_SIZE(med)=%.0f KiB x%.0f -> %.1f MB   WRITE_SIZE(med)=%.0f KiB -> %.1f MB"
