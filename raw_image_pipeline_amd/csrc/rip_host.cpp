@@ -654,9 +654,10 @@ inline int quantise_map(float v) {
 inline int sat_s16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 }  // namespace
 
-size_t remap_tile_lds_bytes(int w, int h) {
+size_t remap_tile_lds_bytes(int x0, int w, int h) {
   if (w <= 0 || h <= 0) return 0;
-  size_t pitch = (((size_t)w * 3 + 15 + 12) + 15) & ~(size_t)15;  // chunk-aligned start + 12 B read slack
+  // rows start at the 16-byte chunk that holds byte 3 * x0 and end with the chunk that holds the last byte
+  size_t pitch = ((((size_t)x0 * 3) & 15) + (size_t)w * 3 + 15) & ~(size_t)15;
   return pitch * (size_t)h;
 }
 
@@ -748,7 +749,7 @@ void compile_remap_plan(RemapPlan& plan, const float* map_xy, int drows, int dco
   for (const RemapTile& tile : plan.tiles) {
     plan.max_rect_w = std::max(plan.max_rect_w, tile.w);
     plan.max_rect_h = std::max(plan.max_rect_h, tile.h);
-    plan.max_lds_bytes = std::max(plan.max_lds_bytes, remap_tile_lds_bytes(tile.w, tile.h));
+    plan.max_lds_bytes = std::max(plan.max_lds_bytes, remap_tile_lds_bytes(tile.x0, tile.w, tile.h));
   }
   plan.valid = true;
 }

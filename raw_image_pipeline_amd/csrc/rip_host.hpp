@@ -155,7 +155,7 @@ struct RemapPlan {
   bool valid = false;
 };
 // LDS bytes the kernel needs for a source rectangle w x h of 3-byte pixels
-size_t remap_tile_lds_bytes(int w, int h);
+size_t remap_tile_lds_bytes(int x0, int w, int h);
 void compile_remap_plan(RemapPlan& plan, const float* map_xy, int drows, int dcols, int src_rows, int src_cols);
 
 // ---------------------------------------------------------------------------------------------

@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
     const bool in_image = yd < b.drows && xd < b.dcols;
     const unsigned xbyte0 = (unsigned)d.x0 * 3u;
     const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
-    const unsigned pitch = ((unsigned)d.w * 3u + 15u + 12u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
+    const unsigned pitch = (ph + (unsigned)d.w * 3u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
     const unsigned chunks = pitch >> 4;
     const unsigned total = d.w > 0 ? chunks * (unsigned)d.h : 0u;
     const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
@@ -1768,7 +1768,7 @@ __global__ __launch_bounds__(kBlock) void remap_ring_kernel(RemapTiledParams p) 
     const bool in_image = yd < b.drows && xd < b.dcols;
     const unsigned xbyte0 = (unsigned)d.x0 * 3u;
     const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
-    const unsigned pitch = ((unsigned)d.w * 3u + 15u + 12u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
+    const unsigned pitch = (ph + (unsigned)d.w * 3u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
     const unsigned chunks = pitch >> 4;
     const unsigned total = d.w > 0 ? chunks * (unsigned)d.h : 0u;
     const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
@@ -1982,7 +1982,10 @@ void launch_stats(const StatsParams& p, hipStream_t stream) {
     // (pca: sum of squares) is 64 lanes * 8 px * 255^2 * pairs_per_task: 128 pairs keep it below 2^32
     const int groups = p.cols / 4, n_pairs = p.rows / 2;
     const int col_waves = (groups + 63) / 64;
-    const int target_tasks = std::max(8, tune_env("RIP_STATS_BLOCKS", 2048) * 4 / std::max(1, std::min(p.n_frames, 16)));
+    // per frame: 512 wave tasks when the batch fills the chip anyway, at most 1024 for a single frame (more
+    // tasks only queue up on the three 64-bit atomics every workgroup ends with: 22 -> 12.6 us for one frame)
+    const int budget = tune_env("RIP_STATS_BLOCKS", 2048) * 4;
+    const int target_tasks = std::max(8, std::min(budget / 8, budget / std::max(1, std::min(p.n_frames, 16))));
     int pairs_per_task = std::max(2, (int)(((long long)col_waves * n_pairs + target_tasks - 1) / target_tasks));
     pairs_per_task = std::min((pairs_per_task + 1) & ~1, 128);  // even: the kernel consumes two pairs per iteration
     const int n_tasks = col_waves * ((n_pairs + pairs_per_task - 1) / pairs_per_task);
@@ -2056,7 +2059,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
     const int pre = chunks <= 1u * kBlock ? 1 : (chunks <= 2u * kBlock ? 2 : 4);
     const unsigned stage_bytes = (unsigned)pre * kBlock * 16u;
     q.stages = std::max(2, std::min(4, stages_env));
-    const unsigned lds = (unsigned)q.stages * stage_bytes;
+    const unsigned lds = (unsigned)q.stages * stage_bytes + 16u;  // the three-dword tap reads run up to 11 B past a row
     const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 4), (int)((160u * 1024u) / (lds + 256u))));
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
     blocks = std::max(8, blocks / 8 * 8);
@@ -2072,7 +2075,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
     // rectangles larger than 4 * kBlock chunks (strong local magnification) or RIP_REMAP_RING=0 (A/B runs)
     int pre = !ring_env && b.n_frames >= 2 && chunks <= 2u * kBlock ? 2 : 0;
     q.double_buffer = pre > 0 ? 1 : 0;
-    const unsigned lds = q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes;
+    const unsigned lds = (q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes) + 16u;
     const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
     blocks = std::max(8, blocks / 8 * 8);
