@@ -866,6 +866,101 @@ __global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, Item
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bayer input with a 90 / 270 degree flip (flip.cpp:45-60: transpose + flip == cv::rotate).  Same
+// window / SWAR demosaic / per-pixel stages as chain_fast_kernel, stage set decided at run time.  A
+// 4x2 item lands as four 2-pixel (6-byte) pieces in four output rows, so the lanes of a workgroup are
+// laid out 4 column groups x 64 row pairs: for one output row the 16 row pairs a wave holds write 96
+// contiguous bytes (and the four waves of the workgroup 384), while each source row is still read in
+// 16..24-byte runs.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store6(__amdgpu_buffer_rsrc_t frame, unsigned off, uint32_t first, uint32_t second) {
+  // two packed pixels (b | g << 8 | r << 16) as three 16-bit stores: the address is only 2-byte aligned
+  const uint32_t lo = first | (second << 24), hi = second >> 8;
+  __builtin_amdgcn_raw_buffer_store_b16((short)(lo & 0xffffu), frame, (int)off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b16((short)(lo >> 16), frame, (int)off + 2, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b16((short)(hi & 0xffffu), frame, (int)off + 4, 0, 0);
+}
+
+__global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int tiles_x, int tiles_per_frame) {
+  __shared__ LdsTabs<ST_CC | ST_GAMMA | ST_VIG | ST_HSV> tb;
+  __shared__ uint8_t s_gamma[256];  // LdsTabs<...VIG> folds gamma into lin_tab; the plain LUT is needed too
+  __shared__ float s_fwd[9];
+  __shared__ int s_inv[6];
+  tb.load(p.tabs);
+  s_gamma[threadIdx.x] = p.tabs->gamma_lut[threadIdx.x];
+  if (threadIdx.x < 9) {
+    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
+    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
+  }
+  __syncthreads();
+  const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
+  const bool rot90 = p.flip_angle == 90;
+  const bool vig = (p.stage_bits & ST_VIG) != 0, gam = (p.stage_bits & ST_GAMMA) != 0;
+  const int groups = p.cols >> 2, pairs = p.rows >> 1;
+  const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
+  const unsigned dst_bytes = __umul24((unsigned)(p.drows - 1), (unsigned)p.dst_step) + (unsigned)p.dcols * 3u;
+  const unsigned tap_bytes = __umul24((unsigned)p.drows, (unsigned)p.dcols) * 3u;
+  const bool has_tap = p.tap != nullptr;
+  for (int tile = blockIdx.x; tile < tiles_per_frame; tile += gridDim.x) {
+    const int tpy = tile / tiles_x, tgx = tile - tpy * tiles_x;
+    const int grp = tgx * 4 + (int)(threadIdx.x & 3u), pair = tpy * 64 + (int)(threadIdx.x >> 2);
+    if (grp >= groups || pair >= pairs) continue;
+    const int y0 = pair * 2, x0 = grp * 4;
+    // source (ys, xs) -> 90: (xs, R-1-ys);  270: (C-1-xs, ys)   [oracle/rip_oracle.c ripo_flip]
+    const int col_d = rot90 ? p.rows - 2 - y0 : y0;  // left one of the two destination columns
+    unsigned dst_off[4], tap_off[4];
+    float mask[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int row_d = rot90 ? x0 + k : p.cols - 1 - (x0 + k);
+      dst_off[k] = __umul24((unsigned)row_d, (unsigned)p.dst_step) + (unsigned)col_d * 3u;
+      tap_off[k] = (__umul24((unsigned)row_d, (unsigned)p.dcols) + (unsigned)col_d) * 3u;
+#pragma unroll
+      for (int ly = 0; ly < 2; ly++) mask[ly][k] = vig ? vignette_mask(p, row_d, rot90 ? col_d + 1 - ly : col_d + ly) : 1.0f;
+    }
+    const WindowOffsets wo = window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0);
+    for (int frame = f_begin; frame < f_end; frame++) {
+      const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
+      const __amdgpu_buffer_rsrc_t dst = frame_rsrc(p.dst + (size_t)frame * p.dst_frame_stride, dst_bytes);
+      const __amdgpu_buffer_rsrc_t tap = frame_rsrc(has_tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr, has_tap ? tap_bytes : 0u);
+      FrameWb w;
+      if (p.wb_mode != WB_NONE) w = p.wb[frame];
+      Window win;
+      load_window(src, wo, win);
+      Planar rowpx[2];
+      debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
+      uint32_t raw[2][4], pix[2][4];  // b | g << 8 | r << 16
+#pragma unroll
+      for (int ly = 0; ly < 2; ly++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int b = (int)((rowpx[ly].b >> (8 * k)) & 0xFFu), g = (int)((rowpx[ly].g >> (8 * k)) & 0xFFu),
+              r = (int)((rowpx[ly].r >> (8 * k)) & 0xFFu);
+          raw[ly][k] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+          apply_wb(p.wb_mode, w, b, g, r);
+          if (p.stage_bits & ST_CC) apply_cc(p, b, g, r);
+          if (vig) {
+            apply_vignette(p, tb, s_fwd, s_inv, mask[ly][k], b, g, r);
+          } else if (gam) {
+            b = s_gamma[b];
+            g = s_gamma[g];
+            r = s_gamma[r];
+          }
+          if (p.stage_bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+          pix[ly][k] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+        }
+      const int first = rot90 ? 1 : 0;  // which source row lands in the left destination column
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (has_tap) store6(tap, tap_off[k], first ? raw[1][k] : raw[0][k], first ? raw[0][k] : raw[1][k]);
+        store6(dst, dst_off[k], first ? pix[1][k] : pix[0][k], first ? pix[0][k] : pix[1][k]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // statistics kernels (grey-world sums, pca sums/maxima): integer reductions, wave64 shuffles
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
@@ -1939,8 +2034,26 @@ int chain_uses_fast_path(const ChainParams& p) {
          p.dst_frame_stride % 4 == 0 && aligned4(p.dst) && (!p.tap || (aligned4(p.tap) && p.tap_frame_stride % 4 == 0));
 }
 
+bool chain_uses_rot_path(const ChainParams& p) {
+  return bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
+         (p.flip_angle == 90 || p.flip_angle == 270) && p.channels == 3 && p.drows == p.cols && p.dcols == p.rows &&
+         p.dst_step % 2 == 0 && p.dst_step < (1u << 24) && p.cols < (1 << 23) &&
+         (unsigned long long)p.dst_step * (unsigned long long)p.drows < (1ull << 32) && p.dst_frame_stride % 2 == 0 &&
+         (reinterpret_cast<uintptr_t>(p.dst) & 1u) == 0 &&
+         (!p.tap || ((reinterpret_cast<uintptr_t>(p.tap) & 1u) == 0 && p.tap_frame_stride % 2 == 0));
+}
+
 void launch_chain(const ChainParams& p, hipStream_t stream) {
   if (p.n_frames <= 0) return;
+  if (chain_uses_rot_path(p)) {
+    const int tiles_x = (p.cols / 4 + 3) / 4, tiles_y = (p.rows / 2 + 63) / 64;
+    const int tiles = tiles_x * tiles_y;
+    const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
+    const int blocks = std::min(cap, tiles);
+    const int groups = std::max(1, std::min(p.n_frames, cap / blocks));
+    hipLaunchKernelGGL(chain_rot_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, tiles_x, tiles);
+    return;
+  }
   if (chain_uses_fast_path(p)) {
     ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
     const int items = (p.rows / 2) * (p.cols / 4);

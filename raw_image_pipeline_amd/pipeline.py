@@ -40,7 +40,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("RIP_LIBRARY") or LIB_PATH  # RIP_LIBRARY: A/B runs of two builds on one GPU box
     try:
         # torch bundles its own libamdhip64 (same soname as ROCm's): import it first so that this
         # library binds to the SAME HIP runtime -- device pointers and streams are shared with torch.

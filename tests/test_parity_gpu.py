@@ -179,6 +179,31 @@ def test_undistortion_batch_through_the_lds_ring(gpu_pipe, oracle, monkeypatch, 
         assert_images_equal(out[i], ref, "ring frame %d (fov %g, %d stages)" % (i, fov, stages))
 
 
+@pytest.mark.parametrize("angle", [90, 270])
+@pytest.mark.parametrize("size,pattern", [((160, 120), "bayer_rggb8"), ((152, 100), "bayer_grbg8"), ((264, 130), "bayer_bggr8")])
+def test_full_chain_with_quarter_turn_flips(gpu_pipe, oracle, angle, size, pattern):
+    """90 / 270 degree flips of Bayer input take the rotated fast kernel (6-byte column pieces); sizes with and
+    without whole 4-group x 64-pair workgroup tiles, taps included, then a batch on the device."""
+    import torch
+    w, h = size
+    cam = synth.camera_model(h, w)  # the image is h wide after the flip
+    c = full_chain_cfg(w, h, flip_angle=angle, cam=cam, ce=True, ce_sat=1.2)
+    configure(gpu_pipe, c)
+    frame = synth.gen_frame(w, h, pattern, seed=77, kind="scene")
+    got = gpu_pipe.process(frame, pattern)
+    ref, enc, t_deb, t_col = oracle_run(oracle, c, frame, pattern, taps=True)
+    assert got.shape == (w, h, 3)
+    assert_images_equal(got, ref, "final")
+    assert_images_equal(gpu_pipe.get_dist_debayered_image(), t_deb.reshape(w, h, 3), "debayered tap")
+    assert_images_equal(gpu_pipe.get_dist_color_image(), t_col.reshape(w, h, 3), "colour tap")
+    frames = np.stack([synth.gen_frame(w, h, pattern, seed=500 + i, kind="uniform") for i in range(3)])
+    out = gpu_pipe.apply_device(torch.from_numpy(frames).cuda(), pattern)
+    torch.cuda.synchronize()
+    for i in range(3):
+        ref, _ = oracle_run(oracle, c, frames[i], pattern)
+        assert_images_equal(out[i].cpu().numpy(), ref, "batch frame %d" % i)
+
+
 def full_chain_cfg(w, h, **kw):
     base = dict(flip=True, flip_angle=180, wb=True, wb_method="grey_world", cc=True, gamma=True, gamma_k=0.8, vig=True,
                 undistort=True, cam=synth.camera_model(w, h))
