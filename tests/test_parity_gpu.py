@@ -246,6 +246,44 @@ def test_full_chain_on_colour_input(gpu_pipe, oracle, encoding, wb, size):
     run_both(gpu_pipe, oracle, c2, img, encoding, 0, what="colour input no-vignette %s %s %s" % (encoding, wb, size))
 
 
+@pytest.mark.parametrize("wb", ["grey_world", "pca", "simple", "none"])
+def test_batch_with_many_frames_per_workgroup(gpu_pipe, oracle, monkeypatch, wb):
+    """Frames are the innermost loop of the chain and remap kernels.  Small grids (environment caps) make every
+    workgroup walk several frames of the batch, as it does at the benchmark's size: each frame must still equal
+    the oracle's single-frame result."""
+    import torch
+    monkeypatch.setenv("RIP_CHAIN_BLOCKS", "8")
+    monkeypatch.setenv("RIP_STATS_BLOCKS", "8")
+    monkeypatch.setenv("RIP_REMAP_PER_CU", "1")
+    w, h, n = 448, 272, 9
+    c = full_chain_cfg(w, h, wb=(wb != "none"), wb_method=wb if wb != "none" else "grey_world", ce=True, ce_sat=1.1)
+    configure(gpu_pipe, c)
+    frames = np.stack([synth.gen_frame(w, h, "bayer_rggb8", seed=900 + i, kind="scene", tint=(0.6 + 0.03 * i, 1.0, 0.5 + 0.02 * i))
+                       for i in range(n)])
+    out = gpu_pipe.apply_device(torch.from_numpy(frames).cuda(), "bayer_rggb8")
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i in range(n):
+        ref, _ = oracle_run(oracle, c, frames[i], "bayer_rggb8")
+        assert_images_equal(out[i], ref, "frame %d of %d (%s)" % (i, n, wb))
+
+
+def test_full_size_batch_equals_single_frames(gpu_pipe):
+    """Size-independent property at BASELINE's size: a resident batch gives, frame by frame, what the
+    single-frame call gives (which test_full_chain_full_size_2448x2048 checks against the oracle)."""
+    import torch
+    w, h, n = 2448, 2048, 6
+    configure(gpu_pipe, full_chain_cfg(w, h))
+    frames = [synth.gen_frame(w, h, "bayer_rggb8", seed=40 + i, kind="scene", tint=(0.65 + 0.05 * i, 1.0, 0.55)) for i in range(3)]
+    singles = [gpu_pipe.process(f, "bayer_rggb8") for f in frames]
+    batch = torch.from_numpy(np.stack([frames[i % 3] for i in range(n)])).cuda()
+    out = gpu_pipe.apply_device(batch, "bayer_rggb8")
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[i], singles[i % 3]), "batch frame %d differs from the single-frame result" % i
+
+
 def test_full_chain_full_size_2448x2048(gpu_pipe, oracle):
     """BASELINE configs[1] at its real size, against the oracle (a few seconds of CPU)."""
     w, h = 2448, 2048
