@@ -1,6 +1,6 @@
 // rip_api.cpp -- implementation of the C-ABI declared in include/rip.h: one handle owns the
 // module parameters (rip_host.hpp), the device-resident constants and scratch, and enqueues the
-// kernels of rip_kernels.hip on the caller's HIP stream.  There is no CPU execution path.
+// kernels of rip_chain/stats/ccc/remap.hip on the caller's HIP stream.  There is no CPU execution path.
 #include "../../include/rip.h"
 
 #include <hip/hip_runtime.h>

@@ -1,0 +1,220 @@
+// rip_ccc.hip -- convolutional colour constancy estimator: log-chroma histogram, 256 x 256 FFT convolution with the
+// model, arg-max (convolutional_color_constancy.cpp:91-340).
+// Shared device code and the stage-by-stage reference citations: rip_device.hpp.
+#include "rip_device.hpp"
+
+namespace rip {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// ccc estimator: resize-sample -> log-chroma histogram -> FFT convolution -> argmax
+// ------------------------------------------------------------------------------------------------
+// colour of the post-flip image at (yd, xd)
+__device__ __forceinline__ void fetch_flipped(const SrcView& s, int angle, int yd, int xd, int& b, int& g, int& r) {
+  int ys, xs;
+  unflip(angle, s.rows, s.cols, yd, xd, ys, xs);
+  fetch_src(s, ys, xs, b, g, r);
+}
+
+__global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
+  const int frame = blockIdx.y;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= 360 * 270) return;
+  const int dy = i / 360, dx = i - dy * 360;
+  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
+  int sm[3];
+  if (p.geom.area_fast) {
+    int acc[3] = {2, 2, 2};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      int b, g, r;
+      fetch_flipped(s, p.flip_angle, 2 * dy + (t >> 1), 2 * dx + (t & 1), b, g, r);
+      acc[0] += b;
+      acc[1] += g;
+      acc[2] += r;
+    }
+    sm[0] = acc[0] >> 2;
+    sm[1] = acc[1] >> 2;
+    sm[2] = acc[2] >> 2;
+  } else {
+    // cv::resize INTER_LINEAR, 8U: Q11 coefficients, two-pass integer arithmetic
+    const int sx = p.geom.xofs[dx];
+    const int sx1 = sx + 1 < p.dcols ? sx + 1 : sx;
+    const int a0 = p.geom.ialpha[dx * 2], a1 = p.geom.ialpha[dx * 2 + 1];
+    const int y0 = p.geom.yofs[dy * 2], y1 = p.geom.yofs[dy * 2 + 1];
+    const int b0 = p.geom.ibeta[dy * 2], b1 = p.geom.ibeta[dy * 2 + 1];
+    int p00[3], p01[3], p10[3], p11[3];
+    fetch_flipped(s, p.flip_angle, y0, sx, p00[0], p00[1], p00[2]);
+    fetch_flipped(s, p.flip_angle, y0, sx1, p01[0], p01[1], p01[2]);
+    fetch_flipped(s, p.flip_angle, y1, sx, p10[0], p10[1], p10[2]);
+    fetch_flipped(s, p.flip_angle, y1, sx1, p11[0], p11[1], p11[2]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      int r0 = p00[c] * a0 + p01[c] * a1;
+      int r1 = p10[c] * a0 + p11[c] * a1;
+      sm[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    }
+  }
+  // calculateHistogramFeature (:210-271)
+  float fb = (float)sm[0], fg = (float)sm[1], fr = (float)sm[2];
+  float gray = fb * 0.114f + fg * 0.587f + fr * 0.299f;
+  bool ok = !(gray > p.upper) && (gray > p.lower);
+  if (sm[0] == 0 || sm[1] == 0 || sm[2] == 0) ok = false;  // log(0) = -inf is skipped
+  if (!ok) return;
+  const float bin_size = 1.0f / 64.0f, uv0 = -1.421875f;
+  float lb = p.tabs->log_tab[sm[0]], lg = p.tabs->log_tab[sm[1]], lr = p.tabs->log_tab[sm[2]];
+  int u = (int)roundf((lg - lr - uv0) / bin_size);
+  int v = (int)roundf((lg - lb - uv0) / bin_size);
+  u = clampi(u, 0, 255);
+  v = clampi(v, 0, 255);
+  atomicAdd(&p.hist_counts[(size_t)frame * 65536 + u * 256 + v], 1u);
+}
+
+// 256-point radix-2 DIT FFT in LDS, 128 threads, same butterfly order as the host reference
+// (rip_host.cpp host_fft256).  re/im hold bit-reversed input on entry.
+__device__ __forceinline__ unsigned bitrev8(unsigned x) { return __brev(x) >> 24; }
+
+__device__ __forceinline__ void fft256_lds(float* re, float* im, const float* twr, const float* twi, bool inverse) {
+  const int b = threadIdx.x;  // butterfly index 0..127
+  for (int len = 2; len <= 256; len <<= 1) {
+    const int half = len >> 1, tstep = 256 / len;
+    const int k = b & (half - 1), lo = (b / half) * len + k, hi = lo + half;
+    const float wr = twr[k * tstep], wi = inverse ? -twi[k * tstep] : twi[k * tstep];
+    const float xr = re[hi], xi = im[hi];
+    const float tr = wr * xr - wi * xi;
+    const float ti = wr * xi + wi * xr;
+    const float ur = re[lo], ui = im[lo];
+    __syncthreads();
+    re[lo] = ur + tr;
+    im[lo] = ui + ti;
+    re[hi] = ur - tr;
+    im[hi] = ui - ti;
+    __syncthreads();
+  }
+}
+
+// forward FFT of the histogram rows (counts -> float via the sequential-accumulation table)
+__global__ __launch_bounds__(128) void ccc_fft_rows_kernel(CccParams p) {
+  __shared__ float re[256], im[256], twr[128], twi[128];
+  const int row = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
+  twr[t] = p.tabs->tw_re[t];
+  twi[t] = p.tabs->tw_im[t];
+  const unsigned int* h = p.hist_counts + (size_t)frame * 65536 + row * 256;
+  for (int i = t; i < 256; i += 128) {
+    unsigned j = bitrev8((unsigned)i);
+    re[j] = p.accum_tab[h[i]];
+    im[j] = 0.f;
+  }
+  __syncthreads();
+  fft256_lds(re, im, twr, twi, false);
+  float2* out = reinterpret_cast<float2*>(p.work) + (size_t)frame * 65536 + row * 256;
+  for (int i = t; i < 256; i += 128) out[i] = make_float2(re[i], im[i]);
+}
+
+// forward FFT of a column, spectrum product + bias, inverse FFT of the column
+__global__ __launch_bounds__(128) void ccc_fft_cols_kernel(CccParams p) {
+  __shared__ float re[256], im[256], twr[128], twi[128], tr[256], ti[256];
+  const int col = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
+  twr[t] = p.tabs->tw_re[t];
+  twi[t] = p.tabs->tw_im[t];
+  float2* data = reinterpret_cast<float2*>(p.work) + (size_t)frame * 65536 + col;
+  for (int i = t; i < 256; i += 128) {
+    float2 v = data[(size_t)i * 256];
+    unsigned j = bitrev8((unsigned)i);
+    re[j] = v.x;
+    im[j] = v.y;
+  }
+  __syncthreads();
+  fft256_lds(re, im, twr, twi, false);
+  const float2* F = reinterpret_cast<const float2*>(p.filter_fft) + col;
+  const float2* B = reinterpret_cast<const float2*>(p.bias_fft) + col;
+  for (int i = t; i < 256; i += 128) {
+    float2 f = F[(size_t)i * 256], bb = B[(size_t)i * 256];
+    float ar = f.x, ai = f.y, br = re[i], bi = im[i];
+    float pr = ar * br - ai * bi;  // mulSpectrums, no conjugation
+    float pi = ar * bi + ai * br;
+    unsigned j = bitrev8((unsigned)i);
+    tr[j] = pr + bb.x;
+    ti[j] = pi + bb.y;
+  }
+  __syncthreads();
+  fft256_lds(tr, ti, twr, twi, true);
+  for (int i = t; i < 256; i += 128) data[(size_t)i * 256] = make_float2(tr[i], ti[i]);
+}
+
+// inverse FFT of the rows; per-row first maximum of the real part
+__global__ __launch_bounds__(128) void ccc_ifft_rows_kernel(CccParams p) {
+  __shared__ float re[256], im[256], twr[128], twi[128];
+  __shared__ float bv[128];
+  __shared__ int bi[128];
+  const int row = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
+  twr[t] = p.tabs->tw_re[t];
+  twi[t] = p.tabs->tw_im[t];
+  const float2* in = reinterpret_cast<const float2*>(p.work) + (size_t)frame * 65536 + row * 256;
+  for (int i = t; i < 256; i += 128) {
+    float2 v = in[i];
+    unsigned j = bitrev8((unsigned)i);
+    re[j] = v.x;
+    im[j] = v.y;
+  }
+  __syncthreads();
+  fft256_lds(re, im, twr, twi, true);
+  float v0 = re[t], v1 = re[t + 128];
+  bv[t] = v1 > v0 ? v1 : v0;
+  bi[t] = v1 > v0 ? t + 128 : t;
+  __syncthreads();
+  for (int off = 64; off > 0; off >>= 1) {
+    if (t < off) {
+      float ov = bv[t + off];
+      int oi = bi[t + off];
+      if (ov > bv[t] || (ov == bv[t] && oi < bi[t])) {
+        bv[t] = ov;
+        bi[t] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    p.row_best[((size_t)frame * 256 + row) * 2] = bv[0];
+    p.row_best[((size_t)frame * 256 + row) * 2 + 1] = (float)bi[0];
+  }
+}
+
+// cv::minMaxLoc: first maximum in row-major order -> Point(x = column, y = row)
+__global__ __launch_bounds__(256) void ccc_argmax_kernel(CccParams p) {
+  __shared__ float bv[256];
+  __shared__ int br[256];
+  const int frame = blockIdx.x, t = threadIdx.x;
+  bv[t] = p.row_best[((size_t)frame * 256 + t) * 2];
+  br[t] = t;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) {
+      float ov = bv[t + off];
+      int orow = br[t + off];
+      if (ov > bv[t] || (ov == bv[t] && orow < br[t])) {
+        bv[t] = ov;
+        br[t] = orow;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    int row = br[0];
+    p.argmax[2 * frame] = (int)p.row_best[((size_t)frame * 256 + row) * 2 + 1];
+    p.argmax[2 * frame + 1] = row;
+  }
+}
+
+}  // namespace
+
+void launch_ccc_estimate(const CccParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  hipLaunchKernelGGL(ccc_hist_kernel, dim3((360 * 270 + kBlock - 1) / kBlock, p.n_frames), dim3(kBlock), 0, stream, p);
+  hipLaunchKernelGGL(ccc_fft_rows_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
+  hipLaunchKernelGGL(ccc_fft_cols_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
+  hipLaunchKernelGGL(ccc_ifft_rows_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
+  hipLaunchKernelGGL(ccc_argmax_kernel, dim3(p.n_frames), dim3(256), 0, stream, p);
+}
+
+}  // namespace rip

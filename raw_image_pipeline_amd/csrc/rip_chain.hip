@@ -1,0 +1,400 @@
+// rip_chain.hip -- the fused per-pixel chain (debayer -> flip -> white-balance gains -> 3x3 -> gamma -> vignetting -> HSV):
+// ONE kernel, 1 B/px read, 3 B/px written, tables in LDS, no intermediate image between the stages.
+// Shared device code and the stage-by-stage reference citations: rip_device.hpp.
+#include "rip_device.hpp"
+
+namespace rip {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// generic chain kernel: one thread per destination pixel; any input kind, size, pitch, flip
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
+  const int frame = blockIdx.y;
+  const long long npix = (long long)p.drows * p.dcols;
+  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
+  GlobalTabs tb{p.tabs};
+  FrameWb w;
+  if (p.wb_mode != WB_NONE) w = p.wb[frame];
+  float fwdf[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) fwdf[k] = (float)p.tabs->lab_fwd[k];
+  uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+  uint8_t* tap = p.tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
+    int yd = (int)(i / p.dcols), xd = (int)(i - (long long)yd * p.dcols);
+    int ys, xs;
+    unflip(p.flip_angle, p.rows, p.cols, yd, xd, ys, xs);
+    int b, g, r;
+    fetch_src(s, ys, xs, b, g, r);
+    if (p.channels == 1) {
+      // mono pass-through: only flip, gamma (cv::LUT is channel-agnostic) and remap apply
+      if (tap) tap[(size_t)yd * p.dcols + xd] = (uint8_t)g;
+      if (p.stage_bits & ST_GAMMA) g = p.tabs->gamma_lut[g];
+      dst[(size_t)yd * p.dst_step + xd] = (uint8_t)g;
+      continue;
+    }
+    if (tap) {
+      uint8_t* t = tap + ((size_t)yd * p.dcols + xd) * 3;
+      t[0] = (uint8_t)b;
+      t[1] = (uint8_t)g;
+      t[2] = (uint8_t)r;
+    }
+    pointwise<-1, -1>(p, w, tb, fwdf, p.tabs->lab_inv_pk, (p.stage_bits & ST_VIG) ? vignette_mask(p, yd, xd) : 1.0f, b, g, r);
+    uint8_t* o = dst + (size_t)yd * p.dst_step + (size_t)xd * 3;
+    o[0] = (uint8_t)b;
+    o[1] = (uint8_t)g;
+    o[2] = (uint8_t)r;
+  }
+}
+
+
+template <int BITS, int WB>
+__global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
+  __shared__ LdsTabs<BITS> tb;
+  __shared__ float s_fwd[9];
+  __shared__ int s_inv[6];
+  tb.load(p.tabs);
+  if (threadIdx.x < 9) {
+    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
+    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
+  }
+  __syncthreads();
+  // Persistent workgroups: the LDS tables are loaded once and amortised over many chunks of
+  // kBlock items.  Block b runs on XCD b % 8 (observed dispatch order; speed only), so each
+  // XCD walks its own contiguous range of chunks and vertically adjacent row pairs -- which
+  // share two halo rows -- hit the same L2.  Frames are the innermost loop: everything that
+  // depends only on the position (item split, vignetting mask in FP64, addresses) is computed
+  // once per item and reused for every frame of the batch.
+  const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
+  // small frames do not fill the chip with one frame's chunks: blockIdx.y splits the batch
+  const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
+  const int per_xcd = (chunks_per_frame + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const bool flip180 = p.flip_angle == 180;
+  for (int ci = blockIdx.x >> 3; ci < per_xcd; ci += gridDim.x >> 3) {
+    const int chunk = xcd * per_xcd + ci;
+    if (chunk >= chunks_per_frame) break;
+    const int item = chunk * kBlock + threadIdx.x;
+    if (item >= items_per_frame) continue;
+    int pair, grp;
+    im.split(item, pair, grp);
+    const int y0 = pair * 2, x0 = grp * 4;
+    const int xbase = flip180 ? p.cols - 4 - x0 : x0;
+    float mask[2][4];
+    unsigned dst_off[2], tap_off[2];
+#pragma unroll
+    for (int ly = 0; ly < 2; ly++) {
+      const int yd = flip180 ? p.rows - 1 - (y0 + ly) : y0 + ly;
+      dst_off[ly] = __umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u;
+      tap_off[ly] = (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u;
+#pragma unroll
+      for (int k = 0; k < 4; k++) mask[ly][k] = (BITS & ST_VIG) ? vignette_mask(p, yd, xbase + k) : 1.0f;
+    }
+    const WindowOffsets wo = window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0);
+    const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
+    const unsigned dst_bytes = __umul24((unsigned)(p.drows - 1), (unsigned)p.dst_step) + (unsigned)p.dcols * 3u;
+    const unsigned tap_bytes = __umul24((unsigned)p.drows, (unsigned)p.dcols) * 3u;
+    for (int frame = f_begin; frame < f_end; frame++) {
+      const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
+      const __amdgpu_buffer_rsrc_t dst = frame_rsrc(p.dst + (size_t)frame * p.dst_frame_stride, dst_bytes);
+      const bool has_tap = p.tap != nullptr;
+      const __amdgpu_buffer_rsrc_t tap = frame_rsrc(has_tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr, has_tap ? tap_bytes : 0u);
+      FrameWb w;
+      if (WB != WB_NONE) w = p.wb[frame];
+      Window win;
+      load_window(src, wo, win);
+      Planar rowpx[2];
+      debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
+#pragma unroll
+      for (int ly = 0; ly < 2; ly++) {
+        Planar v = rowpx[ly];
+        if (flip180) {  // the group is written mirrored: reverse the four pixels
+          keep_branch();
+          v.b = __builtin_bswap32(v.b);
+          v.g = __builtin_bswap32(v.g);
+          v.r = __builtin_bswap32(v.r);
+        }
+        Pack3 raw;
+        const bool need_raw = has_tap || (BITS == 0 && WB == WB_NONE);
+        if (need_raw) interleave4(v, raw.a, raw.b, raw.c);
+        if (has_tap) store12(tap, tap_off[ly], raw);
+        if (BITS == 0 && WB == WB_NONE) {
+          store12(dst, dst_off[ly], raw);  // pure demosaic: no per-pixel stage
+          continue;
+        }
+        if (WB == WB_Q8) {  // grey-world gains on the packed bytes, two pixels per multiply
+          v.b = gains_q8_swar(v.b, (unsigned)w.q8[0]);
+          v.g = gains_q8_swar(v.g, (unsigned)w.q8[1]);
+          v.r = gains_q8_swar(v.r, (unsigned)w.q8[2]);
+        }
+        int q[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          q[k][0] = (int)((v.b >> (8 * k)) & 0xFFu);
+          q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
+          q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
+          pointwise<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, s_fwd, s_inv, mask[ly][k], q[k][0], q[k][1], q[k][2]);
+        }
+        store12(dst, dst_off[ly], pack4(q));
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// colour-input path (bgr8 / rgb8 frames, e.g. the reference's Python demo): 4 px per lane, 12-byte
+// loads and stores, flip 0/180, stage set decided at run time (wave-uniform branches), all tables in LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, ItemMap im, int items_per_frame) {
+  __shared__ LdsTabs<ST_CC | ST_GAMMA | ST_VIG | ST_HSV> tb;
+  __shared__ uint8_t s_gamma[256];  // LdsTabs<...VIG> folds gamma into lin_tab; the plain LUT is needed too
+  __shared__ float s_fwd[9];
+  __shared__ int s_inv[6];
+  tb.load(p.tabs);
+  s_gamma[threadIdx.x] = p.tabs->gamma_lut[threadIdx.x];
+  if (threadIdx.x < 9) {
+    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
+    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
+  }
+  __syncthreads();
+  const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
+  const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
+  const bool flip180 = p.flip_angle == 180;
+  const bool rgb = p.src_kind == SRC_RGB;
+  const bool vig = (p.stage_bits & ST_VIG) != 0, gam = (p.stage_bits & ST_GAMMA) != 0;
+  for (int chunk = blockIdx.x; chunk < chunks_per_frame; chunk += gridDim.x) {
+    const int item = chunk * kBlock + threadIdx.x;
+    if (item >= items_per_frame) continue;
+    int ys, grp;
+    im.split(item, ys, grp);
+    const int x0 = grp * 4;
+    const int yd = flip180 ? p.rows - 1 - ys : ys;
+    const int xbase = flip180 ? p.cols - 4 - x0 : x0;
+    float mask[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) mask[k] = vig ? vignette_mask(p, yd, xbase + k) : 1.0f;
+    const unsigned src_off = __umul24((unsigned)ys, (unsigned)p.src_step) + (unsigned)x0 * 3u;
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u;
+    const unsigned tap_off = (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u;
+    for (int frame = f_begin; frame < f_end; frame++) {
+      const uint3 in = *reinterpret_cast<const uint3*>(p.src + (size_t)frame * p.src_frame_stride + src_off);
+      FrameWb w;
+      if (p.wb_mode != WB_NONE) w = p.wb[frame];
+      int s[4][3], q[4][3];
+      unpack12(in, rgb, s);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) q[k][c] = flip180 ? s[3 - k][c] : s[k][c];
+      if (p.tap) store12(p.tap + (size_t)frame * p.tap_frame_stride + tap_off, pack4(q));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int b = q[k][0], g = q[k][1], r = q[k][2];
+        apply_wb(p.wb_mode, w, b, g, r);
+        if (p.stage_bits & ST_CC) apply_cc(p, b, g, r);
+        if (vig) {
+          apply_vignette(p, tb, s_fwd, s_inv, mask[k], b, g, r);
+        } else if (gam) {
+          b = s_gamma[b];
+          g = s_gamma[g];
+          r = s_gamma[r];
+        }
+        if (p.stage_bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+        q[k][0] = b;
+        q[k][1] = g;
+        q[k][2] = r;
+      }
+      store12(p.dst + (size_t)frame * p.dst_frame_stride + dst_off, pack4(q));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bayer input with a 90 / 270 degree flip (flip.cpp:45-60: transpose + flip == cv::rotate).  Same
+// window / SWAR demosaic / per-pixel stages as chain_fast_kernel, stage set decided at run time.  A
+// 4x2 item lands as four 2-pixel (6-byte) pieces in four output rows, so the lanes of a workgroup are
+// laid out 4 column groups x 64 row pairs: for one output row the 16 row pairs a wave holds write 96
+// contiguous bytes (and the four waves of the workgroup 384), while each source row is still read in
+// 16..24-byte runs.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store6(__amdgpu_buffer_rsrc_t frame, unsigned off, uint32_t first, uint32_t second) {
+  // two packed pixels (b | g << 8 | r << 16) as three 16-bit stores: the address is only 2-byte aligned
+  const uint32_t lo = first | (second << 24), hi = second >> 8;
+  __builtin_amdgcn_raw_buffer_store_b16((short)(lo & 0xffffu), frame, (int)off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b16((short)(lo >> 16), frame, (int)off + 2, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b16((short)(hi & 0xffffu), frame, (int)off + 4, 0, 0);
+}
+
+__global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int tiles_x, int tiles_per_frame) {
+  __shared__ LdsTabs<ST_CC | ST_GAMMA | ST_VIG | ST_HSV> tb;
+  __shared__ uint8_t s_gamma[256];  // LdsTabs<...VIG> folds gamma into lin_tab; the plain LUT is needed too
+  __shared__ float s_fwd[9];
+  __shared__ int s_inv[6];
+  tb.load(p.tabs);
+  s_gamma[threadIdx.x] = p.tabs->gamma_lut[threadIdx.x];
+  if (threadIdx.x < 9) {
+    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
+    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
+  }
+  __syncthreads();
+  const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
+  const bool rot90 = p.flip_angle == 90;
+  const bool vig = (p.stage_bits & ST_VIG) != 0, gam = (p.stage_bits & ST_GAMMA) != 0;
+  const int groups = p.cols >> 2, pairs = p.rows >> 1;
+  const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
+  const unsigned dst_bytes = __umul24((unsigned)(p.drows - 1), (unsigned)p.dst_step) + (unsigned)p.dcols * 3u;
+  const unsigned tap_bytes = __umul24((unsigned)p.drows, (unsigned)p.dcols) * 3u;
+  const bool has_tap = p.tap != nullptr;
+  for (int tile = blockIdx.x; tile < tiles_per_frame; tile += gridDim.x) {
+    const int tpy = tile / tiles_x, tgx = tile - tpy * tiles_x;
+    const int grp = tgx * 4 + (int)(threadIdx.x & 3u), pair = tpy * 64 + (int)(threadIdx.x >> 2);
+    if (grp >= groups || pair >= pairs) continue;
+    const int y0 = pair * 2, x0 = grp * 4;
+    // source (ys, xs) -> 90: (xs, R-1-ys);  270: (C-1-xs, ys)   [oracle/rip_oracle.c ripo_flip]
+    const int col_d = rot90 ? p.rows - 2 - y0 : y0;  // left one of the two destination columns
+    unsigned dst_off[4], tap_off[4];
+    float mask[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int row_d = rot90 ? x0 + k : p.cols - 1 - (x0 + k);
+      dst_off[k] = __umul24((unsigned)row_d, (unsigned)p.dst_step) + (unsigned)col_d * 3u;
+      tap_off[k] = (__umul24((unsigned)row_d, (unsigned)p.dcols) + (unsigned)col_d) * 3u;
+#pragma unroll
+      for (int ly = 0; ly < 2; ly++) mask[ly][k] = vig ? vignette_mask(p, row_d, rot90 ? col_d + 1 - ly : col_d + ly) : 1.0f;
+    }
+    const WindowOffsets wo = window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0);
+    for (int frame = f_begin; frame < f_end; frame++) {
+      const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
+      const __amdgpu_buffer_rsrc_t dst = frame_rsrc(p.dst + (size_t)frame * p.dst_frame_stride, dst_bytes);
+      const __amdgpu_buffer_rsrc_t tap = frame_rsrc(has_tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr, has_tap ? tap_bytes : 0u);
+      FrameWb w;
+      if (p.wb_mode != WB_NONE) w = p.wb[frame];
+      Window win;
+      load_window(src, wo, win);
+      Planar rowpx[2];
+      debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
+      uint32_t raw[2][4], pix[2][4];  // b | g << 8 | r << 16
+#pragma unroll
+      for (int ly = 0; ly < 2; ly++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int b = (int)((rowpx[ly].b >> (8 * k)) & 0xFFu), g = (int)((rowpx[ly].g >> (8 * k)) & 0xFFu),
+              r = (int)((rowpx[ly].r >> (8 * k)) & 0xFFu);
+          raw[ly][k] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+          apply_wb(p.wb_mode, w, b, g, r);
+          if (p.stage_bits & ST_CC) apply_cc(p, b, g, r);
+          if (vig) {
+            apply_vignette(p, tb, s_fwd, s_inv, mask[ly][k], b, g, r);
+          } else if (gam) {
+            b = s_gamma[b];
+            g = s_gamma[g];
+            r = s_gamma[r];
+          }
+          if (p.stage_bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+          pix[ly][k] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+        }
+      const int first = rot90 ? 1 : 0;  // which source row lands in the left destination column
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (has_tap) store6(tap, tap_off[k], first ? raw[1][k] : raw[0][k], first ? raw[0][k] : raw[1][k]);
+        store6(dst, dst_off[k], first ? pix[1][k] : pix[0][k], first ? pix[0][k] : pix[1][k]);
+      }
+    }
+  }
+}
+
+
+template <int BITS, int WB>
+void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL((chain_fast_kernel<BITS, WB>), grid, dim3(kBlock), 0, stream, p, im, items);
+}
+
+template <int BITS>
+void launch_fast_wb(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
+  switch (p.wb_mode) {
+    case WB_Q8: launch_fast<BITS, WB_Q8>(p, im, items, grid, stream); break;
+    case WB_FLOAT: launch_fast<BITS, WB_FLOAT>(p, im, items, grid, stream); break;
+    case WB_PCA: launch_fast<BITS, WB_PCA>(p, im, items, grid, stream); break;
+    case WB_SIMPLE: launch_fast<BITS, WB_SIMPLE>(p, im, items, grid, stream); break;
+    default: launch_fast<BITS, WB_NONE>(p, im, items, grid, stream); break;
+  }
+}
+
+}  // namespace
+
+bool color_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, int rows, int cols, int kind) {
+  return (kind == SRC_BGR || kind == SRC_RGB) && cols % 4 == 0 && step % 4 == 0 && frame_stride % 4 == 0 && aligned4(src) &&
+         step < (1u << 24) && rows < (1 << 23) && (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
+}
+
+bool chain_uses_color_path(const ChainParams& p) {
+  return color_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
+         (p.flip_angle == 0 || p.flip_angle == 180) && p.channels == 3 && p.dst_step % 4 == 0 && p.dst_step < (1u << 24) &&
+         (unsigned long long)p.dst_step * (unsigned long long)p.drows < (1ull << 32) && p.dst_frame_stride % 4 == 0 &&
+         aligned4(p.dst) && (!p.tap || (aligned4(p.tap) && p.tap_frame_stride % 4 == 0));
+}
+
+int chain_uses_fast_path(const ChainParams& p) {
+  return bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
+         (p.flip_angle == 0 || p.flip_angle == 180) && p.channels == 3 && p.dst_step % 4 == 0 &&
+         p.dst_step < (1u << 24) && (unsigned long long)p.dst_step * (unsigned long long)p.drows < (1ull << 32) &&
+         p.dst_frame_stride % 4 == 0 && aligned4(p.dst) && (!p.tap || (aligned4(p.tap) && p.tap_frame_stride % 4 == 0));
+}
+
+bool chain_uses_rot_path(const ChainParams& p) {
+  return bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
+         (p.flip_angle == 90 || p.flip_angle == 270) && p.channels == 3 && p.drows == p.cols && p.dcols == p.rows &&
+         p.dst_step % 2 == 0 && p.dst_step < (1u << 24) && p.cols < (1 << 23) &&
+         (unsigned long long)p.dst_step * (unsigned long long)p.drows < (1ull << 32) && p.dst_frame_stride % 2 == 0 &&
+         (reinterpret_cast<uintptr_t>(p.dst) & 1u) == 0 &&
+         (!p.tap || ((reinterpret_cast<uintptr_t>(p.tap) & 1u) == 0 && p.tap_frame_stride % 2 == 0));
+}
+
+void launch_chain(const ChainParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  if (chain_uses_rot_path(p)) {
+    const int tiles_x = (p.cols / 4 + 3) / 4, tiles_y = (p.rows / 2 + 63) / 64;
+    const int tiles = tiles_x * tiles_y;
+    const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
+    const int blocks = std::min(cap, tiles);
+    const int groups = std::max(1, std::min(p.n_frames, cap / blocks));
+    hipLaunchKernelGGL(chain_rot_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, tiles_x, tiles);
+    return;
+  }
+  if (chain_uses_fast_path(p)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = (p.rows / 2) * (p.cols / 4);
+    const long long chunks = (long long)((items + kBlock - 1) / kBlock);
+    // persistent grid: at most 256 CUs x 8 workgroups, a multiple of 8 (one share per XCD)
+    const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
+    int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
+    const int groups = std::max(1, std::min(p.n_frames, cap / blocks));
+    dim3 grid(blocks, groups);
+    switch (p.stage_bits & 15) {
+#define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream); break;
+      RIP_CASE(0) RIP_CASE(1) RIP_CASE(2) RIP_CASE(3) RIP_CASE(4) RIP_CASE(5) RIP_CASE(6) RIP_CASE(7)
+      RIP_CASE(8) RIP_CASE(9) RIP_CASE(10) RIP_CASE(11) RIP_CASE(12) RIP_CASE(13) RIP_CASE(14) RIP_CASE(15)
+#undef RIP_CASE
+    }
+    return;
+  }
+  if (chain_uses_color_path(p)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = p.rows * (p.cols / 4);
+    const int chunks = (items + kBlock - 1) / kBlock;
+    const int blocks = std::min(2048, chunks);
+    const int groups = std::max(1, std::min(p.n_frames, 2048 / blocks));
+    hipLaunchKernelGGL(chain_color_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, im, items);
+    return;
+  }
+  long long npix = (long long)p.drows * p.dcols;
+  dim3 grid(grid_blocks_for(npix, 2048), p.n_frames);
+  hipLaunchKernelGGL(chain_generic_kernel, grid, dim3(kBlock), 0, stream, p);
+}
+
+}  // namespace rip

@@ -1,0 +1,692 @@
+// rip_device.hpp -- device-side building blocks shared by the kernel translation units
+// (rip_chain.hip, rip_stats.hip, rip_ccc.hip, rip_remap.hip): source views, LDS / global table
+// accessors, the per-pixel stages, the Bayer window and its SWAR demosaic, packing and buffer-resource
+// addressing helpers, and the small host-side launch helpers.  Everything lives in an anonymous
+// namespace: each translation unit gets its own copy and hipcc inlines it.
+//
+// Stage semantics follow the reference's CPU/OpenCV path (file:line relative to the reference tree):
+//   debayer   raw_image_pipeline/src/raw_image_pipeline/modules/debayer.cpp:45-79
+//   flip      .../modules/flip.cpp:37-58
+//   wb        .../modules/white_balance.cpp:59-64 (grey world), :73-136 (pca), :52-57 (simple),
+//             raw_image_pipeline_white_balance/src/.../convolutional_color_constancy.cpp:91-113 (ccc)
+//   colour    .../modules/color_calibration.cpp:91-104
+//   gamma     .../modules/gamma_correction.cpp:35-60
+//   vignette  .../modules/vignetting_correction.cpp:32-93
+//   hsv       .../modules/color_enhancer.cpp:38-47
+//   remap     .../modules/undistortion.cpp:240-245
+// Layout: everything is uint8 interleaved BGR in HBM.  Compile with -ffp-contract=off: the float
+// stages reproduce OpenCV's separate mul/add.
+#pragma once
+#include "rip_kernels.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+
+namespace rip {
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sat_round_u8(float v) {
+  // saturate_cast<uchar>(float) = round half to even, clamp to [0,255], NaN -> 0: exactly
+  // v_cvt_pk_u8_f32 (checked on gfx950 by tools/probes/cvt_pk_u8_probe.hip)
+  return (int)__builtin_amdgcn_cvt_pk_u8_f32(v, 0, 0u);
+}
+// 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate).  Operands must fit 24 bits.
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+// a*b + c as ONE v_mad_i32_i24 (hipcc otherwise splits multiply-add chains into mul, mul, mad, add3)
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ unsigned umulhi24(unsigned a, unsigned b) {
+  return (unsigned)(((unsigned long long)(a & 0xffffffu) * (unsigned long long)(b & 0xffffffu)) >> 32);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+// Put inside a wave-uniform `if` body: the empty volatile asm cannot be speculated, so hipcc keeps the
+// scalar branch instead of computing both sides and selecting per lane with v_cndmask.
+__device__ __forceinline__ void keep_branch() { asm volatile(""); }
+
+struct SrcView {
+  const uint8_t* base;
+  size_t step;
+  int rows, cols, kind, ry, rx;
+};
+
+// Bilinear demosaic at one position with OpenCV's border rule (the interior formula evaluated
+// at the position clamped to [1, n-2]).
+__device__ __forceinline__ void debayer_at(const SrcView& s, int y, int x, int& b, int& g, int& r) {
+  int yc = clampi(y, 1, s.rows - 2), xc = clampi(x, 1, s.cols - 2);
+  const uint8_t* p = s.base + (size_t)yc * s.step + xc;
+  const ptrdiff_t st = (ptrdiff_t)s.step;
+  int dy = (yc - s.ry) & 1, dx = (xc - s.rx) & 1;  // (0,0): R site, (1,1): B site
+  int c = p[0];
+  if (dy != dx) {
+    int h = (p[-1] + p[1] + 1) >> 1;
+    int v = (p[-st] + p[st] + 1) >> 1;
+    g = c;
+    if (dy == 0) {
+      r = h;
+      b = v;
+    } else {
+      b = h;
+      r = v;
+    }
+  } else {
+    int x4 = (p[-1] + p[1] + p[-st] + p[st] + 2) >> 2;
+    int d4 = (p[-st - 1] + p[-st + 1] + p[st - 1] + p[st + 1] + 2) >> 2;
+    g = x4;
+    if (dy == 0) {
+      r = c;
+      b = d4;
+    } else {
+      b = c;
+      r = d4;
+    }
+  }
+}
+
+// Colour of the (pre-flip) source image at (y,x) for any supported input kind.
+__device__ __forceinline__ void fetch_src(const SrcView& s, int y, int x, int& b, int& g, int& r) {
+  if (s.kind == SRC_BAYER) {
+    debayer_at(s, y, x, b, g, r);
+  } else if (s.kind == SRC_MONO) {
+    b = g = r = s.base[(size_t)y * s.step + x];
+  } else {
+    const uint8_t* p = s.base + (size_t)y * s.step + (size_t)x * 3;
+    int c0 = p[0], c1 = p[1], c2 = p[2];
+    g = c1;
+    if (s.kind == SRC_RGB) {  // cvtColor(RGB2BGR), debayer.cpp:72-73
+      b = c2;
+      r = c0;
+    } else {
+      b = c0;
+      r = c2;
+    }
+  }
+}
+
+// destination (post-flip) -> source coordinates, flip.cpp:37-58
+__device__ __forceinline__ void unflip(int angle, int rows, int cols, int yd, int xd, int& ys, int& xs) {
+  if (angle == 180) {
+    ys = rows - 1 - yd;
+    xs = cols - 1 - xd;
+  } else if (angle == 90) {
+    ys = rows - 1 - xd;
+    xs = yd;
+  } else if (angle == 270) {
+    ys = xd;
+    xs = cols - 1 - yd;
+  } else {
+    ys = yd;
+    xs = xd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// table accessors: global (generic kernel) or LDS (fast kernel)
+// ------------------------------------------------------------------------------------------------
+struct GlobalTabs {
+  const DevTables* t;
+  __device__ __forceinline__ int gamma(int i) const { return t->gamma_lut[i]; }
+
+  __device__ __forceinline__ unsigned yf(int i) const { return t->yf_tab[i]; }
+  __device__ __forceinline__ int invg(int i) const { return t->inv_gamma[i]; }
+  __device__ __forceinline__ int sdiv(int i) const { return t->sdiv[i]; }
+  __device__ __forceinline__ int hdiv(int i) const { return t->hdiv[i]; }
+  __device__ __forceinline__ float linf(int i) const { return (float)t->lin_tab[i]; }
+  __device__ __forceinline__ float cbrtf(unsigned i) const { return (float)t->cbrt_tab[i]; }
+};
+
+template <bool ON, typename T, int N>
+struct LdsArr {
+  T v[N];
+};
+template <typename T, int N>
+struct LdsArr<false, T, N> {
+  T v[1];
+};
+
+template <int BITS>
+struct LdsTabs {
+  static constexpr bool kVig = (BITS & ST_VIG) != 0;
+  static constexpr bool kHsv = (BITS & ST_HSV) != 0;
+  // gamma bytes are only needed when the gamma result itself is consumed (not folded into lin_tab)
+  static constexpr bool kGamma = (BITS & ST_GAMMA) != 0 && !kVig;
+  LdsArr<kGamma, uint8_t, 256> gamma_;
+  LdsArr<kVig, float, 256> lin_;    // exact small integers held as float: the Lab forward sums run
+  LdsArr<kVig, float, 3072> cbrt_;  // on v_fma_f32 (2 cycles) instead of v_mad_i32_i24 (4 cycles)
+  LdsArr<kVig, uint32_t, 256> yf_;
+  LdsArr<kVig, uint8_t, 4096> invg_;
+  LdsArr<kHsv, int32_t, 256> sdiv_;
+  LdsArr<kHsv, int32_t, 256> hdiv_;
+  __device__ __forceinline__ int gamma(int i) const { return gamma_.v[i]; }
+  __device__ __forceinline__ float linf(int i) const { return lin_.v[i]; }
+  __device__ __forceinline__ float cbrtf(unsigned i) const { return cbrt_.v[i]; }
+  __device__ __forceinline__ unsigned yf(int i) const { return yf_.v[i]; }
+  __device__ __forceinline__ int invg(int i) const { return invg_.v[i]; }
+  __device__ __forceinline__ int sdiv(int i) const { return sdiv_.v[i]; }
+  __device__ __forceinline__ int hdiv(int i) const { return hdiv_.v[i]; }
+
+  template <typename T, int N>
+  static __device__ __forceinline__ void copy(T (&dst)[N], const T* src) {
+    static_assert((N * sizeof(T)) % 4 == 0, "table size");
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    for (int i = threadIdx.x; i < (int)(N * sizeof(T) / 4); i += kBlock) d[i] = s[i];
+  }
+  __device__ __forceinline__ void load(const DevTables* t) {
+    if constexpr (kGamma) copy(gamma_.v, t->gamma_lut);
+    if constexpr (kVig) {
+      for (int i = threadIdx.x; i < 256; i += kBlock) lin_.v[i] = (float)t->lin_tab[i];
+      for (int i = threadIdx.x; i < 3072; i += kBlock) cbrt_.v[i] = (float)t->cbrt_tab[i];
+      copy(yf_.v, t->yf_tab);
+      copy(invg_.v, t->inv_gamma);
+    }
+    if constexpr (kHsv) {
+      copy(sdiv_.v, t->sdiv);
+      copy(hdiv_.v, t->hdiv);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// per-pixel stages
+// ------------------------------------------------------------------------------------------------
+// white_balance.cpp: grey-world applyChannelGains (Q8, truncating), ccc cv::multiply (float,
+// round-half-even), pca quadratic on B and R.
+__device__ __forceinline__ void apply_wb(int mode, const FrameWb& w, int& b, int& g, int& r) {
+  if (mode == WB_Q8) {
+    b = (b * w.q8[0]) >> 8;
+    g = (g * w.q8[1]) >> 8;
+    r = (r * w.q8[2]) >> 8;
+  } else if (mode == WB_FLOAT) {
+    b = sat_round_u8((float)b * w.fg[0]);
+    g = sat_round_u8((float)g * w.fg[1]);
+    r = sat_round_u8((float)r * w.fg[2]);
+  } else if (mode == WB_SIMPLE) {
+    // SimpleWB's stretch: convertTo(8U, alpha, beta) = saturate(float(x) * alpha + beta), no FMA
+    b = sat_round_u8((float)b * w.fg[0] + w.pca[0]);
+    g = sat_round_u8((float)g * w.fg[1] + w.pca[1]);
+    r = sat_round_u8((float)r * w.fg[2] + w.pca[2]);
+  } else if (mode == WB_PCA) {
+    float fb = (float)b, fr = (float)r;
+    float b2 = fb * fb, r2 = fr * fr;
+    float bp = b2 * w.pca[0] + fb * w.pca[1];
+    float rp = r2 * w.pca[2] + fr * w.pca[3];
+    bp = bp > 255.f ? 255.f : bp;  // THRESH_TRUNC
+    rp = rp > 255.f ? 255.f : rp;
+    b = sat_round_u8(bp);
+    r = sat_round_u8(rp);
+  }
+}
+
+// color_calibration.cpp:93-103: ((m0*B + m1*G) + m2*R) + bias in float32, no FMA
+__device__ __forceinline__ void apply_cc(const ChainParams& p, int& b, int& g, int& r) {
+  float fb = (float)b, fg = (float)g, fr = (float)r;
+  float o[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) o[c] = fb * p.cc_m[c * 3] + fg * p.cc_m[c * 3 + 1] + fr * p.cc_m[c * 3 + 2];
+  // t + 0.0f == t (up to the sign of zero, which the saturating conversion drops): the usual all-zero
+  // bias costs nothing; the test is wave-uniform (kernel arguments)
+  if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
+    keep_branch();
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = o[c] + p.cc_bias[c];
+  }
+  b = sat_round_u8(o[0]);
+  g = sat_round_u8(o[1]);
+  r = sat_round_u8(o[2]);
+}
+
+// vignetting mask value at destination pixel (row, col): vignetting_correction.cpp:32-63
+__device__ __forceinline__ float vignette_mask(const ChainParams& p, int row, int col) {
+  int dx2 = 2 * col - p.dcols, dy2 = 2 * row - p.drows;
+  double s = (double)(mul24(dx2, dx2) + mul24(dy2, dy2)) * 0.25;  // exact (|dx2|, |dy2| < 2^23)
+  double s2 = s * s;
+  double k = s * p.vig_a2 + s2 * p.vig_a4;
+  float m = (float)k;
+  if (p.vig_has_max) m = m * p.vig_inv_max;
+  m = m * p.vig_scale;
+  m = m + 1.0f;
+  return m;
+}
+
+// abToXZ_b[i - minABvalue] (OpenCV color_lab.cpp initLabTabs), evaluated arithmetically.
+// i > 3390: the cube i*i/BASE*i/BASE;  i <= 3390 (L* below ~8, dark pixels only): the linear segment
+// i*108/841 - 290 with C truncation.
+__device__ __forceinline__ int ab_to_xz_cube(int i) {
+  return mul24(mul24(i, i) >> 14, i) >> 14;  // i in (3390, 28719]: both products < 2^31
+}
+__device__ __forceinline__ int ab_to_xz_linear(int i) {
+  // n = i*108 is in [-879660, 366120]; trunc(n/841) = floor((n + (n<0 ? 840 : 0)) / 841); the floor
+  // division is one v_mul_hi_u32_u24 by ceil(2^32/841) after biasing by 841*1100 (exact below 11.9e6);
+  // BASE*16/116*108/841 == 290
+  int n = mul24(i, 108);
+  n += (n >> 31) & 840;
+  const unsigned q = umulhi24((unsigned)(n + 841 * 1100), 5106977u);
+  return (int)q - (1100 + 290);
+}
+// Both lookups of one pixel.  The linear segment is rare, so it sits behind a wave-uniform branch:
+// hipcc otherwise predicates both sides and issues all of it for every pixel.
+__device__ __forceinline__ void ab_to_xz_pair(int ix, int iz, int& x, int& z) {
+  x = ab_to_xz_cube(ix);
+  z = ab_to_xz_cube(iz);
+  const bool dark = ix <= 3390 || iz <= 3390;
+  if (__builtin_amdgcn_ballot_w64(dark) != 0ull) {
+    if (ix <= 3390) x = ab_to_xz_linear(ix);
+    if (iz <= 3390) z = ab_to_xz_linear(iz);
+  }
+}
+
+// BGR -> 8-bit Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93; RGB2Lab_b /
+// Lab2RGBinteger).  The table `linf` already folds the gamma LUT when the gamma stage is on.
+//
+// The forward half runs on v_fma_f32 (2 cycles per wave64 on gfx950, against 4 for the 24-bit
+// integer multiply-add): every operand is a small integer held exactly in fp32 and every sum stays
+// below 2^23, so the products and sums are exact.  floor(T / 2^n) of an integer T is taken as
+// RN((T + 0.5) / 2^n - 0.5) -- never a tie -- by adding the magic constant 1.5 * 2^23 inside the
+// FMA, which leaves the integer in the low mantissa bits.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+template <typename Tabs>
+__device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs& tb, const float* fwd, const int* inv,
+                                               float mask, int& b, int& g, int& r) {
+  constexpr float kMagic = 12582912.0f;        // 1.5 * 2^23: ulp 1 in [2^23, 2^24)
+  constexpr unsigned kMagicBits = 0x4B400000u;  // bit pattern of kMagic
+  const float v0 = tb.linf(b), v1 = tb.linf(g), v2 = tb.linf(r);
+  // (C . v + 2048) >> 12 == RN((C . v + 0.5) / 4096): sums <= 2040 * 4096 + 0.5 < 2^23
+  const float sx = __builtin_fmaf(v2, fwd[2], __builtin_fmaf(v1, fwd[1], __builtin_fmaf(v0, fwd[0], 0.5f)));
+  const float sy = __builtin_fmaf(v2, fwd[5], __builtin_fmaf(v1, fwd[4], __builtin_fmaf(v0, fwd[3], 0.5f)));
+  const float sz = __builtin_fmaf(v2, fwd[8], __builtin_fmaf(v1, fwd[7], __builtin_fmaf(v0, fwd[6], 0.5f)));
+  const unsigned ix = __float_as_uint(__builtin_fmaf(sx, 1.0f / 4096.0f, kMagic)) - kMagicBits;
+  const unsigned iy = __float_as_uint(__builtin_fmaf(sy, 1.0f / 4096.0f, kMagic)) - kMagicBits;
+  const unsigned iz = __float_as_uint(__builtin_fmaf(sz, 1.0f / 4096.0f, kMagic)) - kMagicBits;
+  const float fX = tb.cbrtf(ix), fY = tb.cbrtf(iy), fZ = tb.cbrtf(iz);
+  // L = (296 fY - 1336935 + 16384) >> 15, in [0, 255] by construction
+  const float tl = __builtin_fmaf(fY, 296.0f, -1336934.5f);  // T + 0.5 - 16384, T = 296 fY - 1320551 >= 0
+  const float Lf = __builtin_fmaf(tl, 1.0f / 32768.0f, kMagic) - kMagic;
+  const int L = sat_round_u8(Lf * mask);  // convertTo(32F), multiply, convertTo(8U)
+  // a = clamp((500 (fX - fY) + 128 * 2^15 + 2^14) >> 15, 0, 255); outside [0, 2^23) the FMA may round,
+  // but those values clamp to the same end of the range anyway
+  const float ta = __builtin_fmaf(fX - fY, 500.0f, 4194304.5f);
+  const float tb2 = __builtin_fmaf(fY - fZ, 200.0f, 4194304.5f);
+  // OpenCV saturates a and b to [0, 255]; over all 2^24 inputs they stay inside [42, 226] and [20, 223]
+  // (exhaustive check: tests/test_oracle_known_answers.py::test_lab_ab_never_saturate), so the clamp is dead.
+  // abits = kMagicBits + a: the 24-bit multiply reads 0x400000 + a, the constant takes 0x400000 * K back
+  // (mod 2^32), leaving a * K + rounding in one v_mad_u32_u24.
+  const unsigned abits = __float_as_uint(__builtin_fmaf(ta, 1.0f / 32768.0f, kMagic));
+  const unsigned bbits = __float_as_uint(__builtin_fmaf(tb2, 1.0f / 32768.0f, kMagic));
+  constexpr unsigned kA = 5u * 53687u, kB = 41943u;
+  const unsigned yf = tb.yf(L);
+  const int y = (int)(yf & 0xffffu), ify = (int)(yf >> 16);
+  const int adiv = (int)((__umul24(abits, kA) + ((1u << 7) - 0x400000u * kA)) >> 13) - 128 * 16384 / 500;
+  const int bdiv = (int)((__umul24(bbits, kB) + ((1u << 4) - 0x400000u * kB)) >> 9) - 128 * 16384 / 200 + 1;
+  int x, z;
+  ab_to_xz_pair(ify + adiv, ify - bdiv, x, z);
+  // x in [-652, 28028] (a in [42, 226], L <= 255) and y in [0, 16384] fit 16 bits, the coefficients too: the
+  // x and y terms of a row are one v_dot2_i32_i16; z reaches 59.9k and stays on the 24-bit multiply-add.
+  // No intermediate leaves 31 bits.  inv = DevTables::lab_inv_pk.
+  const i16x2 xy = {(short)x, (short)y};
+  const int bo = __builtin_amdgcn_sdot2(xy, __builtin_bit_cast(i16x2, inv[0]), mad24(inv[1], z, 1 << 13), false) >> 14;
+  const int go = __builtin_amdgcn_sdot2(xy, __builtin_bit_cast(i16x2, inv[2]), mad24(inv[3], z, 1 << 13), false) >> 14;
+  const int ro = __builtin_amdgcn_sdot2(xy, __builtin_bit_cast(i16x2, inv[4]), mad24(inv[5], z, 1 << 13), false) >> 14;
+  b = tb.invg(clampi(bo, 0, 4095));
+  g = tb.invg(clampi(go, 0, 4095));
+  r = tb.invg(clampi(ro, 0, 4095));
+}
+
+// color_enhancer.cpp:38-47: RGB2HSV_b (H in [0,180)), float gain with u8 saturation,
+// HSV2RGB_b (float)
+template <typename Tabs>
+__device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, int& b, int& g, int& r) {
+  int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+  int diff = v - vmin;
+  int s = (mul24(diff, tb.sdiv(v)) + (1 << 11)) >> 12;
+  int h;
+  if (v == r)
+    h = g - b;
+  else if (v == g)
+    h = b - r + 2 * diff;
+  else
+    h = r - g + 4 * diff;
+  h = (mul24(h, tb.hdiv(diff)) + (1 << 11)) >> 12;
+  h += h < 0 ? 180 : 0;
+  h = clampi(h, 0, 255);
+  int H = sat_round_u8((float)h * p.hsv_gain[0]);
+  int S = sat_round_u8((float)s * p.hsv_gain[1]);
+  int V = sat_round_u8((float)v * p.hsv_gain[2]);
+  float fh = (float)H, fs = (float)S * (1.f / 255.f), fv = (float)V * (1.f / 255.f);
+  float ob, og, orr;
+  if (fs == 0.f) {
+    ob = og = orr = fv;
+  } else {
+    fh = fh * (6.f / 180.f);
+    if (fh >= 6.f) fh = fh - 6.f;  // fmod(h, 6): h <= 255/30 < 12
+    int sector = (int)fh;          // floor, h >= 0
+    fh = fh - (float)sector;
+    if ((unsigned)sector >= 6u) {
+      sector = 0;
+      fh = 0.f;
+    }
+    float t0 = fv;
+    float t1 = fv * (1.f - fs);
+    float t2 = fv * (1.f - fs * fh);
+    float t3 = fv * (1.f - fs * (1.f - fh));
+    switch (sector) {
+      case 0: ob = t1; og = t3; orr = t0; break;
+      case 1: ob = t1; og = t0; orr = t2; break;
+      case 2: ob = t3; og = t0; orr = t1; break;
+      case 3: ob = t0; og = t2; orr = t1; break;
+      case 4: ob = t0; og = t1; orr = t3; break;
+      default: ob = t2; og = t1; orr = t0; break;
+    }
+  }
+  b = sat_round_u8(ob * 255.f);
+  g = sat_round_u8(og * 255.f);
+  r = sat_round_u8(orr * 255.f);
+}
+
+// The pointwise chain after flip.  BITS >= 0: compile-time stage set; BITS < 0: runtime.
+template <int BITS, int WB, typename Tabs>
+__device__ __forceinline__ void pointwise(const ChainParams& p, const FrameWb& w, const Tabs& tb, const float* fwd,
+                                          const int* inv, float mask, int& b, int& g, int& r) {
+  const int bits = BITS >= 0 ? BITS : p.stage_bits;
+  apply_wb(WB >= 0 ? WB : p.wb_mode, w, b, g, r);
+  if (bits & ST_CC) apply_cc(p, b, g, r);
+  if (bits & ST_VIG) {
+    // gamma folded into lin_tab by the host
+    apply_vignette(p, tb, fwd, inv, mask, b, g, r);
+  } else if (bits & ST_GAMMA) {
+    b = tb.gamma(b);
+    g = tb.gamma(g);
+    r = tb.gamma(r);
+  }
+  if (bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast path: Bayer input, flip 0/180, cols % 4 == 0, rows % 2 == 0, dword-aligned pitches.
+// One work item = 4 px x 2 rows (two Bayer quads): a 6x4 sample window held in 12 registers
+// (three aligned dwords per row), 24 output bytes stored as two dwordx3.
+// ------------------------------------------------------------------------------------------------
+struct Window {
+  uint32_t w[4][3];  // rows y0-1 .. y0+2; dwords at x0-4, x0, x0+4
+  // sample at window row r, column offset i in [-1, 4] relative to x0
+  __device__ __forceinline__ int at(int r, int i) const {
+    const int idx = 4 + i;
+    return (int)((w[r][idx >> 2] >> (8 * (idx & 3))) & 0xffu);
+  }
+};
+
+// Frames are addressed through buffer resources (uniform base in SGPRs, 32-bit per-lane byte offset
+// in one VGPR): the frame base changes per iteration of the frames loop on the scalar unit, and no
+// 64-bit per-lane address arithmetic is issued on the VALU.  A frame is < 4 GiB (checked by the
+// launchers); reads past `bytes` return 0.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// byte offsets of the window dwords inside a frame: rows y0-1 .. y0+2 (clamped), left dword and
+// centre dword (the right dword is centre + 4 except at the right image edge, where it is the centre)
+struct WindowOffsets {
+  unsigned left[4], centre[4];
+  unsigned right_delta;  // 4, or 0 at the right edge
+};
+__device__ __forceinline__ WindowOffsets window_offsets(unsigned step, int rows, int cols, int y0, int x0) {
+  WindowOffsets o;
+  const int xl = x0 >= 4 ? x0 - 4 : x0;
+  o.right_delta = x0 + 4 < cols ? 4u : 0u;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int y = clampi(y0 - 1 + r, 0, rows - 1);
+    const unsigned row = __umul24((unsigned)y, step);  // 32-bit offsets: a frame is < 4 GiB, a row < 16 MiB
+    o.left[r] = row + (unsigned)xl;
+    o.centre[r] = row + (unsigned)x0;
+  }
+  return o;
+}
+__device__ __forceinline__ void load_window(__amdgpu_buffer_rsrc_t frame, const WindowOffsets& o, Window& win) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    win.w[r][0] = __builtin_amdgcn_raw_buffer_load_b32(frame, (int)o.left[r], 0, 0);
+    win.w[r][1] = __builtin_amdgcn_raw_buffer_load_b32(frame, (int)o.centre[r], 0, 0);
+    win.w[r][2] = __builtin_amdgcn_raw_buffer_load_b32(frame, (int)(o.centre[r] + o.right_delta), 0, 0);
+  }
+}
+
+// Four pixels of one image row as planar byte vectors: byte j of .b/.g/.r = pixel j.
+struct Planar {
+  uint32_t b, g, r;
+};
+__device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// Bilinear demosaic of the 4x2 tile, four pixels per instruction (SWAR): every row of the window is
+// split into its even and odd bytes, widened to 16-bit lanes inside a dword, so one v_add_u32 adds
+// two taps of two pixels and the sums (<= 4*255 + 2) cannot carry across lanes.
+// RY/RX: position of the R sample in the 2x2 cell.  out[ly] = image row y0 + ly.
+// One window row prepared for the SWAR sums: the centre dword, the two shifted views and their
+// even / odd bytes widened to 16-bit lanes.
+struct RowPrep {
+  uint32_t c, wm, wp;        // columns x0 .. x0+3, x0-1 .. x0+2, x0+1 .. x0+4
+  uint32_t hs_lo, hs_hi;     // left + right neighbour of pixels (0, 2) and (1, 3)
+  uint32_t c_lo, c_hi;       // centre bytes of pixels (0, 2) and (1, 3)
+};
+__device__ __forceinline__ RowPrep prep_row(uint32_t left, uint32_t centre, uint32_t right) {
+  constexpr uint32_t M8 = 0x00FF00FFu;
+  RowPrep r;
+  r.c = centre;
+  r.wm = __builtin_amdgcn_alignbyte(centre, left, 3);
+  r.wp = __builtin_amdgcn_alignbyte(right, centre, 1);
+  r.hs_lo = (r.wm & M8) + (r.wp & M8);
+  r.hs_hi = ((r.wm >> 8) & M8) + ((r.wp >> 8) & M8);
+  r.c_lo = centre & M8;
+  r.c_hi = (centre >> 8) & M8;
+  return r;
+}
+
+// One output row (four pixels) from the prepared rows above / at / below it.
+// RED_ROW: the row holds R samples; RX: column parity of the R samples.
+template <bool RED_ROW, int RX>
+__device__ __forceinline__ Planar debayer_row(const RowPrep& up, const RowPrep& at, const RowPrep& dn) {
+  constexpr uint32_t M8 = 0x00FF00FFu;
+  constexpr uint32_t kEven = RX == 0 ? 0x00FF00FFu : 0xFF00FF00u;  // byte lanes with dx == 0
+  // two-tap averages (a + b + 1) >> 1 of all four byte lanes in one v_lerp_u8
+  const uint32_t H = __builtin_amdgcn_lerp(at.wm, at.wp, 0x01010101u);
+  const uint32_t V = __builtin_amdgcn_lerp(up.c, dn.c, 0x01010101u);
+  const uint32_t X4 = (((at.hs_lo + up.c_lo + dn.c_lo + 0x00020002u) >> 2) & M8) |
+                      ((((at.hs_hi + up.c_hi + dn.c_hi + 0x00020002u) >> 2) & M8) << 8);
+  const uint32_t D4 = (((up.hs_lo + dn.hs_lo + 0x00020002u) >> 2) & M8) | ((((up.hs_hi + dn.hs_hi + 0x00020002u) >> 2) & M8) << 8);
+  const uint32_t C = at.c;
+  Planar o;
+  if (RED_ROW) {
+    // red row: dx == 0 -> R site (B = diag, G = cross, R = centre); dx == 1 -> G site (B = vert, R = horiz)
+    o.b = bfi32(kEven, D4, V);
+    o.g = bfi32(kEven, X4, C);
+    o.r = bfi32(kEven, C, H);
+  } else {
+    // blue row: dx == 0 -> G site (B = horiz, R = vert); dx == 1 -> B site (B = centre, G = cross, R = diag)
+    o.b = bfi32(kEven, H, C);
+    o.g = bfi32(kEven, C, X4);
+    o.r = bfi32(kEven, V, D4);
+  }
+  return o;
+}
+
+// Bilinear demosaic of the 4x2 tile, four pixels per instruction (SWAR): every row of the window is
+// split into its even and odd bytes, widened to 16-bit lanes inside a dword, so one v_add_u32 adds
+// two taps of two pixels and the sums (<= 4*255 + 2) cannot carry across lanes.
+// RY/RX: position of the R sample in the 2x2 cell.  out[ly] = image row y0 + ly; r[k] = row y0 - 1 + k.
+template <int RY, int RX>
+__device__ __forceinline__ void debayer_rows(const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3,
+                                             Planar (&out)[2]) {
+  out[0] = debayer_row<RY == 0, RX>(r0, r1, r2);
+  out[1] = debayer_row<RY == 1, RX>(r1, r2, r3);
+}
+template <int RY, int RX>
+__device__ __forceinline__ void debayer_swar(const Window& win, Planar (&out)[2]) {
+  RowPrep r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) r[k] = prep_row(win.w[k][0], win.w[k][1], win.w[k][2]);
+  debayer_rows<RY, RX>(r[0], r[1], r[2], r[3], out);
+}
+
+// OpenCV's border replication on a demosaiced 4x2 tile: column 0 := column 1, column W-1 := W-2,
+// then row 0 := row 1, row H-1 := H-2
+__device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int cols, Planar (&out)[2]) {
+  if (x0 == 0) {
+#pragma unroll
+    for (int ly = 0; ly < 2; ly++) {
+      out[ly].b = (out[ly].b & 0xFFFFFF00u) | ((out[ly].b >> 8) & 0xFFu);
+      out[ly].g = (out[ly].g & 0xFFFFFF00u) | ((out[ly].g >> 8) & 0xFFu);
+      out[ly].r = (out[ly].r & 0xFFFFFF00u) | ((out[ly].r >> 8) & 0xFFu);
+    }
+  }
+  if (x0 + 4 == cols) {
+#pragma unroll
+    for (int ly = 0; ly < 2; ly++) {
+      out[ly].b = (out[ly].b & 0x00FFFFFFu) | ((out[ly].b << 8) & 0xFF000000u);
+      out[ly].g = (out[ly].g & 0x00FFFFFFu) | ((out[ly].g << 8) & 0xFF000000u);
+      out[ly].r = (out[ly].r & 0x00FFFFFFu) | ((out[ly].r << 8) & 0xFF000000u);
+    }
+  }
+  if (y0 == 0) out[0] = out[1];
+  if (y0 + 2 == rows) out[1] = out[0];
+}
+__device__ __forceinline__ void debayer_rows_any(const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3, int ry,
+                                                 int rx, Planar (&out)[2]) {
+  switch (ry * 2 + rx) {
+    case 0: debayer_rows<0, 0>(r0, r1, r2, r3, out); break;
+    case 1: debayer_rows<0, 1>(r0, r1, r2, r3, out); break;
+    case 2: debayer_rows<1, 0>(r0, r1, r2, r3, out); break;
+    default: debayer_rows<1, 1>(r0, r1, r2, r3, out); break;
+  }
+}
+
+// demosaic of the 4x2 tile at (y0, x0) including OpenCV's border replication
+__device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int rx, int y0, int x0, int rows, int cols,
+                                                 Planar (&out)[2]) {
+  switch (ry * 2 + rx) {
+    case 0: debayer_swar<0, 0>(win, out); break;
+    case 1: debayer_swar<0, 1>(win, out); break;
+    case 2: debayer_swar<1, 0>(win, out); break;
+    default: debayer_swar<1, 1>(win, out); break;
+  }
+  debayer_fix_edges(y0, x0, rows, cols, out);
+}
+
+// planar -> interleaved BGR (12 bytes) with six v_perm_b32
+__device__ __forceinline__ void interleave4(const Planar& v, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
+  const uint32_t bg01 = __builtin_amdgcn_perm(v.g, v.b, 0x05010400u);  // B0 G0 B1 G1
+  const uint32_t bg23 = __builtin_amdgcn_perm(v.g, v.b, 0x07030602u);  // B2 G2 B3 G3
+  d0 = __builtin_amdgcn_perm(v.r, bg01, 0x02040100u);                  // B0 G0 R0 B1
+  const uint32_t g1r1 = __builtin_amdgcn_perm(v.r, bg01, 0x00000503u); // G1 R1 . .
+  d1 = __builtin_amdgcn_perm(bg23, g1r1, 0x05040100u);                 // G1 R1 B2 G2
+  d2 = __builtin_amdgcn_perm(v.r, bg23, 0x07030206u);                  // R2 B3 G3 R3
+}
+
+struct Pack3 {
+  uint32_t a, b, c;
+};
+// packs four BGR pixels (in the given order) into 12 bytes
+__device__ __forceinline__ Pack3 pack4(const int (&q)[4][3]) {
+  Pack3 o;
+  o.a = (uint32_t)q[0][0] | ((uint32_t)q[0][1] << 8) | ((uint32_t)q[0][2] << 16) | ((uint32_t)q[1][0] << 24);
+  o.b = (uint32_t)q[1][1] | ((uint32_t)q[1][2] << 8) | ((uint32_t)q[2][0] << 16) | ((uint32_t)q[2][1] << 24);
+  o.c = (uint32_t)q[2][2] | ((uint32_t)q[3][0] << 8) | ((uint32_t)q[3][1] << 16) | ((uint32_t)q[3][2] << 24);
+  return o;
+}
+__device__ __forceinline__ void store12(uint8_t* ptr, const Pack3& v) {
+  uint3 u;
+  u.x = v.a;
+  u.y = v.b;
+  u.z = v.c;
+  *reinterpret_cast<uint3*>(ptr) = u;
+}
+
+__device__ __forceinline__ void store12(__amdgpu_buffer_rsrc_t frame, unsigned off, const Pack3& v) {
+  u32x3 u = {v.a, v.b, v.c};
+  __builtin_amdgcn_raw_buffer_store_b96(u, frame, (int)off, 0, 0);
+}
+
+// Grey-world applyChannelGains (x * q) >> 8 on four packed bytes.  q <= 256 (the gains are normalised
+// by the largest one), so the products of the even and of the odd bytes stay inside their 16-bit
+// lanes and one 24-bit multiply serves two pixels.
+__device__ __forceinline__ uint32_t gains_q8_swar(uint32_t v, unsigned q) {
+  const uint32_t pe = __umul24(v & 0x00FF00FFu, q);
+  const uint32_t po = __umul24((v >> 8) & 0x00FF00FFu, q);
+  return bfi32(0xFF00FF00u, po, pe >> 8);
+}
+
+// item index -> (row pair, 4-px group) without an integer division per item
+struct ItemMap {
+  int groups_per_row;
+  float inv_groups;
+  __device__ __forceinline__ void split(int item, int& pair, int& grp) const {
+    int q = (int)((float)item * inv_groups);
+    int rem = item - q * groups_per_row;
+    if (rem < 0) {
+      q--;
+      rem += groups_per_row;
+    } else if (rem >= groups_per_row) {
+      q++;
+      rem -= groups_per_row;
+    }
+    pair = q;
+    grp = rem;
+  }
+};
+
+// four interleaved pixels (12 bytes) -> ints; rgb8 input is swapped to BGR here (debayer.cpp:72-73)
+__device__ __forceinline__ void unpack12(const uint3& v, bool rgb, int (&q)[4][3]) {
+  const uint32_t w[3] = {v.x, v.y, v.z};
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int byte = k * 3 + c;
+      q[k][c] = (int)((w[byte >> 2] >> (8 * (byte & 3))) & 0xFFu);
+    }
+  if (rgb) {  // cvtColor(RGB2BGR), debayer.cpp:72-73
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int t = q[k][0];
+      q[k][0] = q[k][2];
+      q[k][2] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+int grid_blocks_for(long long work_items, int max_blocks) {
+  long long b = (work_items + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+bool bayer_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, int rows, int cols, int kind) {
+  return kind == SRC_BAYER && cols % 4 == 0 && rows % 2 == 0 && rows >= 4 && cols >= 4 && step % 4 == 0 &&
+         frame_stride % 4 == 0 && aligned4(src) && step < (1u << 24) && rows < (1 << 23) &&
+         (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
+}
+
+// grid-size tunables (persistent workgroups per launch), overridable from the environment for experiments
+int tune_env(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  if (!e || !*e) return dflt;
+  const int v = std::atoi(e);
+  return v >= 8 ? v / 8 * 8 : (v > 0 ? v : dflt);
+}
+
+}  // namespace
+}  // namespace rip

@@ -1,6 +1,6 @@
 // rip_kernels.hpp -- POD parameter blocks and launch entry points of the gfx950 kernels.
 // Everything here is plain data: the API layer (rip_api.cpp) fills the structs, the launchers
-// (rip_kernels.hip) enqueue on the caller's stream.  No allocation, no synchronisation.
+// (rip_chain.hip, rip_stats.hip, rip_ccc.hip, rip_remap.hip; shared device code in rip_device.hpp) enqueue on the caller's stream.  No allocation, no synchronisation.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -169,5 +169,7 @@ void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax
 void launch_remap(const RemapParams& p, hipStream_t stream);
 // Which code path launch_chain would pick (for tests / DESIGN.md): 1 fast, 0 generic.
 int chain_uses_fast_path(const ChainParams& p);
+// bgr8 / rgb8 frames that qualify for the 4-px-per-lane colour kernels (rip_chain.hip)
+bool color_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, int rows, int cols, int kind);
 
 }  // namespace rip

@@ -1,0 +1,529 @@
+// rip_remap.hip -- undistortion remap (cv::remap INTER_LINEAR, BORDER_CONSTANT): LDS-DMA ring over a compiled plan,
+// border patch kernel and the direct-gather fallbacks.
+// Shared device code and the stage-by-stage reference citations: rip_device.hpp.
+#include "rip_device.hpp"
+
+namespace rip {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// remap: cv::remap(INTER_LINEAR, BORDER_CONSTANT 0), undistortion.cpp:240-245
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int round_map(float v) {
+  float s = v * 32.f;
+  if (!(s > -2147483648.f && s < 2147483648.f)) return INT_MIN;  // cvRound of NaN/inf/out of range
+  return (int)__builtin_rintf(s);
+}
+
+// Six consecutive source bytes starting at byte offset `off` of the frame (any alignment), fetched
+// as three aligned dwords (one global_load_dwordx3) and realigned with v_alignbyte_b32.
+// Requires off + 12 <= readable bytes (checked by the caller).
+__device__ __forceinline__ void load6(const uint8_t* frame, unsigned off, uint32_t& lo, uint32_t& hi) {
+  const uint3 v = *reinterpret_cast<const uint3*>(frame + (off & ~3u));
+  lo = __builtin_amdgcn_alignbyte(v.y, v.x, off & 3u);
+  hi = __builtin_amdgcn_alignbyte(v.z, v.y, off & 3u);
+}
+
+struct RemapSrc {
+  const uint8_t* frame;
+  unsigned step;      // bytes per row (< 2^24)
+  unsigned readable;  // bytes that may be read starting at `frame` (to the end of the batch buffer)
+  int rows, cols;
+  bool wide_ok;       // frame base is dword aligned: load6 may be used
+};
+
+template <int CN>
+__device__ __forceinline__ void remap_pixel(const RemapSrc& s, float mx, float my, int (&out)[CN]) {
+  const int sxq = round_map(mx), syq = round_map(my);
+  const int sx = clampi(sxq >> 5, -32768, 32767), sy = clampi(syq >> 5, -32768, 32767);
+  const int fx = sxq & 31, fy = syq & 31;
+  // cv::remap's Q15 bilinear weights 32(32-fx)(32-fy)...; separable form, exact in integers:
+  // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15 == (top*(32-fy) + bot*fy + 512) >> 10
+  const int wx1 = fx, wx0 = 32 - fx, wy1 = fy, wy0 = 32 - fy;
+  if ((unsigned)sx < (unsigned)(s.cols - 1) && (unsigned)sy < (unsigned)(s.rows - 1)) {
+    const unsigned off0 = __umul24((unsigned)sy, s.step) + (unsigned)sx * CN;
+    const unsigned off1 = off0 + s.step;
+    int p0[2 * CN], p1[2 * CN];
+    if (CN == 3 && s.wide_ok && off1 + 12u <= s.readable) {
+      uint32_t l0, h0, l1, h1;
+      load6(s.frame, off0, l0, h0);
+      load6(s.frame, off1, l1, h1);
+      p0[0] = l0 & 0xff; p0[1] = (l0 >> 8) & 0xff; p0[2] = (l0 >> 16) & 0xff; p0[3] = l0 >> 24; p0[4] = h0 & 0xff; p0[5] = (h0 >> 8) & 0xff;
+      p1[0] = l1 & 0xff; p1[1] = (l1 >> 8) & 0xff; p1[2] = (l1 >> 16) & 0xff; p1[3] = l1 >> 24; p1[4] = h1 & 0xff; p1[5] = (h1 >> 8) & 0xff;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2 * CN; k++) {
+        p0[k] = s.frame[off0 + k];
+        p1[k] = s.frame[off1 + k];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+      const int top = mul24(p0[c], wx0) + mul24(p0[CN + c], wx1);
+      const int bot = mul24(p1[c], wx0) + mul24(p1[CN + c], wx1);
+      out[c] = (mul24(top, wy0) + mul24(bot, wy1) + 512) >> 10;  // <= 255: convex combination
+    }
+    return;
+  }
+  if (sx >= s.cols || sx + 1 < 0 || sy >= s.rows || sy + 1 < 0) {
+#pragma unroll
+    for (int c = 0; c < CN; c++) out[c] = 0;
+    return;
+  }
+  // partially outside: taps beyond the image contribute the border constant 0
+  const bool x0 = sx >= 0 && sx < s.cols, x1 = sx + 1 >= 0 && sx + 1 < s.cols;
+  const bool y0 = sy >= 0 && sy < s.rows, y1 = sy + 1 >= 0 && sy + 1 < s.rows;
+#pragma unroll
+  for (int c = 0; c < CN; c++) {
+    const int p00 = (x0 && y0) ? s.frame[(size_t)sy * s.step + (size_t)sx * CN + c] : 0;
+    const int p01 = (x1 && y0) ? s.frame[(size_t)sy * s.step + (size_t)(sx + 1) * CN + c] : 0;
+    const int p10 = (x0 && y1) ? s.frame[(size_t)(sy + 1) * s.step + (size_t)sx * CN + c] : 0;
+    const int p11 = (x1 && y1) ? s.frame[(size_t)(sy + 1) * s.step + (size_t)(sx + 1) * CN + c] : 0;
+    out[c] = (mul24(mul24(p00, wx0) + mul24(p01, wx1), wy0) + mul24(mul24(p10, wx0) + mul24(p11, wx1), wy1) + 512) >> 10;
+  }
+}
+
+__device__ __forceinline__ RemapSrc remap_src(const RemapParams& p, int frame) {
+  RemapSrc s;
+  s.frame = p.src + (size_t)frame * p.src_frame_stride;
+  s.step = (unsigned)p.src_step;
+  const unsigned long long rest = (unsigned long long)(p.n_frames - frame) * p.src_frame_stride;
+  s.readable = rest > 0xffffffffull ? 0xffffffffu : (unsigned)rest;
+  s.rows = p.rows;
+  s.cols = p.cols;
+  s.wide_ok = (reinterpret_cast<uintptr_t>(s.frame) & 3u) == 0;
+  return s;
+}
+
+// 4 destination pixels per thread (CN == 3, dcols % 4 == 0, dword-aligned pitch)
+__global__ __launch_bounds__(kBlock) void remap_vec4_kernel(RemapParams p, ItemMap im, int items_per_frame) {
+  const int frame = blockIdx.y;
+  const RemapSrc s = remap_src(p, frame);
+  uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+  for (int item = blockIdx.x * kBlock + threadIdx.x; item < items_per_frame; item += gridDim.x * kBlock) {
+    int yd, grp;
+    im.split(item, yd, grp);
+    const int xd = grp * 4;
+    const float4* m = reinterpret_cast<const float4*>(p.map_xy + ((size_t)(__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xd)) * 2);
+    const float4 m0 = m[0], m1 = m[1];
+    int q[4][3];
+    remap_pixel<3>(s, m0.x, m0.y, q[0]);
+    remap_pixel<3>(s, m0.z, m0.w, q[1]);
+    remap_pixel<3>(s, m1.x, m1.y, q[2]);
+    remap_pixel<3>(s, m1.z, m1.w, q[3]);
+    store12(dst + (__umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xd * 3u), pack4(q));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiled remap over a compiled plan: one workgroup = one 64x16 destination tile.  The tile's source
+// rectangle is copied into LDS with aligned 16-byte loads (every source byte crosses the memory
+// pipeline once per tile instead of once per tap), the taps are read back from LDS, and the
+// bilinear weights are applied with v_dot4_u32_u8.  The plan word (4 B/px) and the tile descriptor
+// are read once per tile and reused for every frame of the batch.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_load6(const uint8_t* lds, unsigned a, uint32_t& lo, uint32_t& hi) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(lds + (a & ~3u));
+  const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+  lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
+  hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+}
+
+// Destination pixels whose taps straddle the image border (a few thousand per map) are listed by the
+// plan compiler and patched after the tiled kernel by this per-tap kernel, which keeps the heavy
+// border logic out of the tiled kernel's register budget.
+__global__ __launch_bounds__(kBlock) void remap_border_kernel(RemapTiledParams p) {
+  const RemapParams& b = p.base;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.n_border) return;
+  const uint32_t packed = p.border_list[i];
+  const int yd = (int)(packed >> 16), xd = (int)(packed & 0xffffu);
+  const float2 m = reinterpret_cast<const float2*>(b.map_xy)[__umul24((unsigned)yd, (unsigned)b.dcols) + (unsigned)xd];
+  const int frame = blockIdx.y;
+  const RemapSrc s = remap_src(b, frame);
+  int q[3];
+  remap_pixel<3>(s, m.x, m.y, q);
+  uint8_t* d = b.dst + (size_t)frame * b.dst_frame_stride + (__umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u);
+  d[0] = (uint8_t)q[0];
+  d[1] = (uint8_t)q[1];
+  d[2] = (uint8_t)q[2];
+}
+
+// PRE: staging slots (16-byte chunks) per lane held in registers while the previous frame is gathered;
+// 0 = no software pipeline (one LDS buffer, any rectangle size)
+template <int PRE>
+__global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int kPre = PRE > 0 ? PRE : 1;
+  const RemapParams& b = p.base;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 4, lgrp = tid & 15;
+  const unsigned step = (unsigned)b.src_step;
+  const int f_per_group = (b.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(b.n_frames, f_begin + f_per_group);
+  if (f_begin >= f_end) return;  // uniform for the workgroup
+  uint8_t* const buf0 = lds;
+  uint8_t* const buf1 = lds + p.lds_bytes;  // second staging buffer (double_buffer only)
+  for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
+    const int tile = xcd * per_xcd + ti;
+    if (tile >= ntiles) break;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const RemapTileDesc d = p.tiles[tile];
+    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * 1024)[tid];
+    const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
+    const int yd = ty * 16 + lrow, xd = tx * 64 + lgrp * 4;
+    const bool in_image = yd < b.drows && xd < b.dcols;
+    const unsigned xbyte0 = (unsigned)d.x0 * 3u;
+    const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
+    const unsigned pitch = (ph + (unsigned)d.w * 3u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
+    const unsigned chunks = pitch >> 4;
+    const unsigned total = d.w > 0 ? chunks * (unsigned)d.h : 0u;
+    const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
+    // frame-invariant part of the plan words: LDS address of the top-left tap and the x weights
+    unsigned tap_addr[4], wxb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t w = words[k];
+      const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u;
+      tap_addr[k] = __umul24(rely, pitch) + relx * 3u + ph;
+      wxb[k] = (32u - fx) | (fx << 24);
+    }
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u;
+
+    auto gather_store = [&](const uint8_t* buf, int f) {
+      if (!in_image) return;
+      int q[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t w = words[k];
+        if (w >= kPlanBorder) {
+          q[k][0] = q[k][1] = q[k][2] = 0;  // outside: border constant; border pixels: patched by remap_border_kernel
+          continue;
+        }
+        uint32_t t0, t1, b0, b1;  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
+        lds_load6(buf, tap_addr[k], t0, t1);
+        lds_load6(buf, tap_addr[k] + pitch, b0, b1);
+        const unsigned fy = w >> 27, wy0 = 32u - fy, wy1 = fy;
+        const unsigned wB = wxb[k], wx0 = wB & 0xffu, wx1 = wB >> 24;
+        const unsigned wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
+        // every row sum starts at 16: 16 * (32 - fy) + 16 * fy = 512 is the rounding term of
+        // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15, exact
+        const unsigned topB = __builtin_amdgcn_udot4(t0, wB, 16u, false);
+        const unsigned topG = __builtin_amdgcn_udot4(t0, wG0, __builtin_amdgcn_udot4(t1, wx1, 16u, false), false);
+        const unsigned topR = __builtin_amdgcn_udot4(t0, wR0, __builtin_amdgcn_udot4(t1, wR1, 16u, false), false);
+        const unsigned botB = __builtin_amdgcn_udot4(b0, wB, 16u, false);
+        const unsigned botG = __builtin_amdgcn_udot4(b0, wG0, __builtin_amdgcn_udot4(b1, wx1, 16u, false), false);
+        const unsigned botR = __builtin_amdgcn_udot4(b0, wR0, __builtin_amdgcn_udot4(b1, wR1, 16u, false), false);
+        q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1)) >> 10);
+        q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1)) >> 10);
+        q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1)) >> 10);
+      }
+      uint8_t* dst = b.dst + (size_t)f * b.dst_frame_stride;
+      store12(dst + dst_off, pack4(q));
+    };
+
+    if (PRE > 0) {
+      // software pipeline: the global loads of frame f+1 are in flight while frame f is gathered out
+      // of the other LDS buffer; one barrier per frame
+      unsigned goff[kPre], loff[kPre];
+#pragma unroll
+      for (int j = 0; j < kPre; j++) {
+        const unsigned i = (unsigned)tid + (unsigned)j * kBlock;
+        int r, c;
+        cm.split((int)i, r, c);
+        goff[j] = i < total ? __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFFFu;
+        loff[j] = __umul24((unsigned)r, pitch) + ((unsigned)c << 4);
+      }
+      uint4 pre[kPre];
+      auto issue = [&](const RemapSrc& s) {
+#pragma unroll
+        for (int j = 0; j < kPre; j++) {
+          pre[j] = make_uint4(0u, 0u, 0u, 0u);
+          if (goff[j] != 0xFFFFFFFFu && goff[j] + 16u <= s.readable) pre[j] = *reinterpret_cast<const uint4*>(s.frame + goff[j]);
+        }
+      };
+      auto commit = [&](uint8_t* buf) {
+#pragma unroll
+        for (int j = 0; j < kPre; j++)
+          if (goff[j] != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(buf + loff[j]) = pre[j];
+      };
+      issue(remap_src(b, f_begin));
+      commit(buf0);
+      __syncthreads();
+      for (int f = f_begin; f < f_end; f++) {
+        uint8_t* cur = ((f - f_begin) & 1) ? buf1 : buf0;
+        uint8_t* nxt = ((f - f_begin) & 1) ? buf0 : buf1;
+        const bool more = f + 1 < f_end;
+        if (more) issue(remap_src(b, f + 1));
+        gather_store(cur, f);
+        if (more) commit(nxt);
+        __syncthreads();
+      }
+    } else {
+      for (int f = f_begin; f < f_end; f++) {
+        const RemapSrc s = remap_src(b, f);
+        for (unsigned i = tid; i < total; i += kBlock) {
+          int r, c;
+          cm.split((int)i, r, c);
+          const unsigned off = __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4);
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (off + 16u <= s.readable) v = *reinterpret_cast<const uint4*>(s.frame + off);
+          *reinterpret_cast<uint4*>(buf0 + (__umul24((unsigned)r, pitch) + ((unsigned)c << 4))) = v;
+        }
+        __syncthreads();
+        gather_store(buf0, f);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring version of the tiled remap: the source rectangle of frame f+D is copied global -> LDS by the
+// LDS-DMA path (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass) while frame f is
+// gathered, D = stages - 1 frames ahead, so the HBM/TLB latency of the 15 MB frame-to-frame stride is
+// covered by D gathers instead of one.  hipcc drains vmcnt to 0 at every barrier when it knows about
+// an LDS-DMA in flight, so the loads are inline asm and counted here: every wave issues exactly PRE
+// loads per frame (lanes past the rectangle load from an out-of-range offset, which the buffer
+// resource turns into zeros), loads of one wave land in order, and "loads of frame f have landed" is
+// s_waitcnt vmcnt((frames issued after f) * PRE) -- stores in flight only make that wait longer.
+// One barrier per frame: after it every wave's part of frame f is in LDS and every wave is done
+// with frame f-1, whose stage is the one refilled next.
+// The staged image is chunk-linear (chunk i of the rectangle at byte 16*i: the row pitch is a whole
+// number of chunks), which is exactly the order LDS-DMA writes (M0 base + lane * 16).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voffset), "s"(rsrc), "s"(lds_wave_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+template <int PRE>
+__global__ __launch_bounds__(kBlock) void remap_ring_kernel(RemapTiledParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr unsigned kStage = (unsigned)PRE * kBlock * 16u;  // bytes per stage
+  const RemapParams& b = p.base;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 4, lgrp = tid & 15;
+  const unsigned step = (unsigned)b.src_step;
+  const int f_per_group = (b.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(b.n_frames, f_begin + f_per_group);
+  if (f_begin >= f_end) return;  // uniform for the workgroup
+  const int nb = p.stages, dist = nb - 1;  // ring size, prefetch distance (2 or 3)
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);
+  const unsigned wave_chunk0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);
+  const unsigned dst_bytes = __umul24((unsigned)(b.drows - 1), (unsigned)b.dst_step) + (unsigned)b.dcols * 3u;
+  for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
+    const int tile = xcd * per_xcd + ti;
+    if (tile >= ntiles) break;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const RemapTileDesc d = p.tiles[tile];
+    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * 1024)[tid];
+    const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
+    const int yd = ty * 16 + lrow, xd = tx * 64 + lgrp * 4;
+    const bool in_image = yd < b.drows && xd < b.dcols;
+    const unsigned xbyte0 = (unsigned)d.x0 * 3u;
+    const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
+    const unsigned pitch = (ph + (unsigned)d.w * 3u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
+    const unsigned chunks = pitch >> 4;
+    const unsigned total = d.w > 0 ? chunks * (unsigned)d.h : 0u;
+    const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
+    // frame-invariant: source offsets of this lane's chunks, LDS address of the top-left tap, weights.
+    // Outside / border pixels gather address 0 with zero weights: 16 * 32 >> 10 == 0 is the border
+    // constant, and remap_border_kernel patches the border pixels afterwards -- no branch per pixel.
+    unsigned goff[PRE];
+#pragma unroll
+    for (int j = 0; j < PRE; j++) {
+      const unsigned i = (unsigned)tid + (unsigned)j * kBlock;
+      int r, c;
+      cm.split((int)i, r, c);
+      goff[j] = i < total ? __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFF0u;
+    }
+    unsigned tap_addr[4], wxb[4], wyy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t w = words[k];
+      const bool live = w < kPlanBorder;
+      const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u, fy = w >> 27;
+      tap_addr[k] = live ? __umul24(rely, pitch) + relx * 3u + ph : 0u;
+      wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
+      wyy[k] = (32u - fy) | (fy << 16);
+    }
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u;
+
+    auto issue = [&](int f, int slot) {
+      const RemapSrc s = remap_src(b, f);
+      const __amdgpu_buffer_rsrc_t rsrc = frame_rsrc(s.frame, s.readable);
+      const unsigned stage = lds0 + (unsigned)slot * kStage;
+#pragma unroll
+      for (int j = 0; j < PRE; j++) lds_dma16(rsrc, goff[j], stage + ((wave_chunk0 + (unsigned)j * kBlock) << 4));
+    };
+    auto gather_store = [&](const uint8_t* buf, int f) {
+      if (!in_image) return;
+      uint32_t t0[4], t1[4], b0[4], b1[4];  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        lds_load6(buf, tap_addr[k], t0[k], t1[k]);
+        lds_load6(buf, tap_addr[k] + pitch, b0[k], b1[k]);
+      }
+      int q[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned wy0 = wyy[k] & 0xffffu, wy1 = wyy[k] >> 16;
+        const unsigned wB = wxb[k], wx0 = wB & 0xffu, wx1 = wB >> 24;
+        const unsigned wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
+        // every row sum starts at 16: 16 * (32 - fy) + 16 * fy = 512 is the rounding term of
+        // ((top*(32-fy) + bot*fy) * 32 + 2^14) >> 15, exact
+        const unsigned topB = __builtin_amdgcn_udot4(t0[k], wB, 16u, false);
+        const unsigned topG = __builtin_amdgcn_udot4(t0[k], wG0, __builtin_amdgcn_udot4(t1[k], wx1, 16u, false), false);
+        const unsigned topR = __builtin_amdgcn_udot4(t0[k], wR0, __builtin_amdgcn_udot4(t1[k], wR1, 16u, false), false);
+        const unsigned botB = __builtin_amdgcn_udot4(b0[k], wB, 16u, false);
+        const unsigned botG = __builtin_amdgcn_udot4(b0[k], wG0, __builtin_amdgcn_udot4(b1[k], wx1, 16u, false), false);
+        const unsigned botR = __builtin_amdgcn_udot4(b0[k], wR0, __builtin_amdgcn_udot4(b1[k], wR1, 16u, false), false);
+        q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1)) >> 10);
+        q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1)) >> 10);
+        q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1)) >> 10);
+      }
+      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, pack4(q));
+    };
+
+    // every earlier memory operation of this wave (plan words, tile descriptor, previous stores) is
+    // waited for here, so the counted waits below see only this tile's ring loads and stores
+    wait_vmcnt<0>();
+    int slot_in = 0, slot_out = 0;  // ring positions of the next frame to issue / to gather
+    for (int f = f_begin; f < f_end && f < f_begin + dist; f++) {
+      issue(f, slot_in);
+      slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
+    }
+    for (int f = f_begin; f < f_end; f++) {
+      const int ahead = min(dist - 1, f_end - 1 - f);  // frames issued after f and still allowed in flight
+      if (ahead >= 2)
+        wait_vmcnt<2 * PRE>();
+      else if (ahead == 1)
+        wait_vmcnt<PRE>();
+      else
+        wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (f + dist < f_end) {
+        issue(f + dist, slot_in);
+        slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
+      }
+      gather_store(lds + (unsigned)slot_out * kStage, f);
+      slot_out = slot_out + 1 == nb ? 0 : slot_out + 1;
+    }
+    __builtin_amdgcn_s_barrier();  // the next tile's prologue refills stages other waves may still be reading
+  }
+}
+
+template <int CN>
+__global__ __launch_bounds__(kBlock) void remap_generic_kernel(RemapParams p) {
+  const int frame = blockIdx.y;
+  const RemapSrc s = remap_src(p, frame);
+  uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+  const long long npix = (long long)p.drows * p.dcols;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
+    int yd = (int)(i / p.dcols), xd = (int)(i - (long long)yd * p.dcols);
+    const float* m = p.map_xy + (size_t)i * 2;
+    int o[CN];
+    remap_pixel<CN>(s, m[0], m[1], o);
+    uint8_t* d = dst + (size_t)yd * p.dst_step + (size_t)xd * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) d[c] = (uint8_t)o[c];
+  }
+}
+
+}  // namespace
+
+bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
+  const RemapParams& b = p.base;
+  if (b.n_frames <= 0) return true;
+  const bool ok = b.channels == 3 && b.dcols % 4 == 0 && b.dst_step % 4 == 0 && b.dst_frame_stride % 4 == 0 && aligned4(b.dst) &&
+                  b.src_step % 16 == 0 && b.src_frame_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(b.src) & 15u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p.words) & 15u) == 0 && b.src_step < (1u << 24) && b.rows < (1 << 23) &&
+                  (unsigned long long)b.src_step * (unsigned long long)b.rows < (1ull << 32) && b.dst_step < (1u << 24) &&
+                  (unsigned long long)b.dst_step * (unsigned long long)b.drows < (1ull << 32) && p.lds_bytes <= 64u * 1024u &&
+                  p.tiles_x * 64 >= b.dcols && p.tiles_y * 16 >= b.drows && b.drows <= 65535 && b.dcols <= 65535;
+  if (!ok) return false;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  // persistent workgroups, a multiple of 8 (one share of the tile range per XCD); LDS bounds residency
+  RemapTiledParams q = p;
+  q.lds_bytes = (std::max(p.lds_bytes, 16u) + 15u) & ~15u;
+  const unsigned chunks = q.lds_bytes / 16u;  // upper bound of the 16-byte chunks of any tile
+  const int ring_env = std::getenv("RIP_REMAP_RING") ? std::atoi(std::getenv("RIP_REMAP_RING")) : 1;
+  // measured on config2 (sweeps in DESIGN.md): 3 stages (two frames ahead) with 4 workgroups per CU; more resident
+  // workgroups fetch more (the source rectangles of neighbouring tiles stop meeting in L2) and run slower
+  const int stages_env = tune_env("RIP_REMAP_STAGES", 3);
+  if (ring_env && chunks <= 4u * kBlock) {
+    // LDS-DMA ring: PRE chunks per lane and frame, `stages` buffers of PRE * 4 KiB
+    const int pre = chunks <= 1u * kBlock ? 1 : (chunks <= 2u * kBlock ? 2 : 4);
+    const unsigned stage_bytes = (unsigned)pre * kBlock * 16u;
+    q.stages = std::max(2, std::min(4, stages_env));
+    const unsigned lds = (unsigned)q.stages * stage_bytes + 16u;  // the three-dword tap reads run up to 11 B past a row
+    const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 4), (int)((160u * 1024u) / (lds + 256u))));
+    int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
+    blocks = std::max(8, blocks / 8 * 8);
+    const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too
+    const dim3 grid(blocks, groups);
+    if (pre == 1)
+      hipLaunchKernelGGL(remap_ring_kernel<1>, grid, dim3(kBlock), lds, stream, q);
+    else if (pre == 2)
+      hipLaunchKernelGGL(remap_ring_kernel<2>, grid, dim3(kBlock), lds, stream, q);
+    else
+      hipLaunchKernelGGL(remap_ring_kernel<4>, grid, dim3(kBlock), lds, stream, q);
+  } else {
+    // rectangles larger than 4 * kBlock chunks (strong local magnification) or RIP_REMAP_RING=0 (A/B runs)
+    int pre = !ring_env && b.n_frames >= 2 && chunks <= 2u * kBlock ? 2 : 0;
+    q.double_buffer = pre > 0 ? 1 : 0;
+    const unsigned lds = (q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes) + 16u;
+    const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
+    int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
+    blocks = std::max(8, blocks / 8 * 8);
+    const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too
+    const dim3 grid(blocks, groups);
+    if (pre == 2)
+      hipLaunchKernelGGL(remap_tiled_kernel<2>, grid, dim3(kBlock), lds, stream, q);
+    else
+      hipLaunchKernelGGL(remap_tiled_kernel<0>, grid, dim3(kBlock), lds, stream, q);
+  }
+  if (q.n_border > 0)
+    hipLaunchKernelGGL(remap_border_kernel, dim3((q.n_border + kBlock - 1) / kBlock, b.n_frames), dim3(kBlock), 0, stream, q);
+  return true;
+}
+
+void launch_remap(const RemapParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  // remap_pixel addresses a source frame with 32-bit offsets and 24-bit multiplies
+  if (p.src_step >= (1u << 24) || p.rows >= (1 << 23) || (unsigned long long)p.src_step * (unsigned long long)p.rows >= (1ull << 32) ||
+      p.dst_step >= (1u << 24) || (unsigned long long)p.dst_step * (unsigned long long)p.drows >= (1ull << 32))
+    return;  // rejected by the API layer before we get here (see rip_api.cpp make_plan)
+  const bool vec = p.channels == 3 && p.dcols % 4 == 0 && p.dst_step % 4 == 0 && p.dst_frame_stride % 4 == 0 &&
+                   aligned4(p.dst) && (reinterpret_cast<uintptr_t>(p.map_xy) & 15u) == 0;
+  if (vec) {
+    ItemMap im{p.dcols / 4, 1.0f / (float)(p.dcols / 4)};
+    const int items = p.drows * (p.dcols / 4);
+    int per_frame = grid_blocks_for(items, std::max(8, 8192 / std::max(1, std::min(p.n_frames, 16))));
+    hipLaunchKernelGGL(remap_vec4_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
+    return;
+  }
+  long long npix = (long long)p.drows * p.dcols;
+  dim3 grid(grid_blocks_for(npix, 4096), p.n_frames);
+  if (p.channels == 3)
+    hipLaunchKernelGGL(remap_generic_kernel<3>, grid, dim3(kBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL(remap_generic_kernel<1>, grid, dim3(kBlock), 0, stream, p);
+}
+
+}  // namespace rip

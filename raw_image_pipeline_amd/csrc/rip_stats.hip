@@ -1,0 +1,437 @@
+// rip_stats.hip -- white-balance statistics (grey-world sums, pca sums / maxima, SimpleWB histograms) and the
+// on-device finalisation of the per-frame gains.
+// Shared device code and the stage-by-stage reference citations: rip_device.hpp.
+#include "rip_device.hpp"
+
+namespace rip {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// statistics kernels (grey-world sums, pca sums/maxima): integer reductions, wave64 shuffles
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned wave_max(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down(v, off, 64));
+  return v;
+}
+
+struct StatAcc {
+  unsigned s[5];
+  unsigned m[3];
+};
+
+__device__ __forceinline__ void stat_add(const StatsParams& p, int b, int g, int r, StatAcc& a, unsigned* s_hist) {
+  if (p.mode == WB_SIMPLE) {
+    // SimpleWB: per-channel 256-bin histograms, privatised in LDS
+    atomicAdd(&s_hist[b], 1u);
+    atomicAdd(&s_hist[256 + g], 1u);
+    atomicAdd(&s_hist[512 + r], 1u);
+  } else if (p.mode == WB_Q8) {
+    // GrayworldWB calculateChannelSums: skip when (max-min)*255 > thresh255*max
+    unsigned mn = (unsigned)min(b, min(g, r)), mx = (unsigned)max(b, max(g, r));
+    if ((mx - mn) * 255u > p.thresh255 * mx) return;
+    a.s[0] += b;
+    a.s[1] += g;
+    a.s[2] += r;
+  } else {
+    a.s[0] += b;
+    a.s[1] += b * b;
+    a.s[2] += r;
+    a.s[3] += r * r;
+    a.s[4] += g;
+    a.m[0] = max(a.m[0], (unsigned)b);
+    a.m[1] = max(a.m[1], (unsigned)r);
+    a.m[2] = max(a.m[2], (unsigned)g);
+  }
+}
+
+__device__ __forceinline__ void stat_hist_init(const StatsParams& p, unsigned* s_hist) {
+  if (p.mode != WB_SIMPLE) return;
+  for (int i = threadIdx.x; i < 768; i += kBlock) s_hist[i] = 0u;
+  __syncthreads();
+}
+
+__device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, FrameStats* out, unsigned* s_hist, int frame) {
+  if (p.mode == WB_SIMPLE) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += kBlock)
+      if (s_hist[i]) atomicAdd(&p.hist3[(size_t)frame * 768 + i], s_hist[i]);
+    return;
+  }
+  __shared__ unsigned sh[8][kBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    unsigned v = wave_sum(a.s[k]);
+    if (lane == 0) sh[k][wid] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    unsigned v = wave_max(a.m[k]);
+    if (lane == 0) sh[5 + k][wid] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    unsigned long long t = 0;
+    for (int i = 0; i < kBlock / 64; i++) t += sh[threadIdx.x][i];
+    if (t) atomicAdd(&out->sum[threadIdx.x], t);
+  } else if (threadIdx.x < 8 && p.mode == WB_PCA) {
+    unsigned t = 0;
+    for (int i = 0; i < kBlock / 64; i++) t = max(t, sh[threadIdx.x][i]);
+    atomicMax(&out->mx[threadIdx.x - 5], t);
+  }
+}
+
+// Grey-world statistics of four planar pixels, two pixels per instruction: the bytes are widened to
+// 16-bit lanes; max/min with v_pk_max/min_u16; both sides of the saturation test
+// (max - min) * 255 > thresh255 * max fit 16 bits (thresh255 <= 255 after the clamp below, which does
+// not change the outcome: for thresh255 >= 255 no pixel is ever skipped); the masked channel sums are
+// one v_dot2_u32_u16 per channel with the 0/1 keep flags as weights.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ void grayworld_add_swar(const Planar& v, unsigned thresh255, StatAcc& a) {
+  constexpr uint32_t M8 = 0x00FF00FFu;
+  const u16x2 t2 = as_u16x2(thresh255 * 0x00010001u), one2 = as_u16x2(0x00010001u);
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const uint32_t bw = (half ? v.b >> 8 : v.b) & M8, gw = (half ? v.g >> 8 : v.g) & M8, rw = (half ? v.r >> 8 : v.r) & M8;
+    const u16x2 b2 = as_u16x2(bw), g2 = as_u16x2(gw), r2 = as_u16x2(rw);
+    const u16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(b2, g2), r2);
+    const u16x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(b2, g2), r2);
+    const uint32_t d = __builtin_bit_cast(uint32_t, mx) - __builtin_bit_cast(uint32_t, mn);  // lane-wise: max >= min
+    const u16x2 lhs = as_u16x2((d << 8) - d);                                                // * 255, <= 65025 per lane
+    const u16x2 rhs = mx * t2;
+    const u16x2 skip = __builtin_elementwise_min(__builtin_elementwise_sub_sat(lhs, rhs), one2);  // 1 where lhs > rhs
+    const u16x2 keep = one2 - skip;
+    a.s[0] = __builtin_amdgcn_udot2(b2, keep, a.s[0], false);
+    a.s[1] = __builtin_amdgcn_udot2(g2, keep, a.s[1], false);
+    a.s[2] = __builtin_amdgcn_udot2(r2, keep, a.s[2], false);
+  }
+}
+
+// Statistics of a Bayer frame.  A wave owns a strip 64 groups (256 px) wide and walks down
+// `pairs_per_task` row pairs of it: the row index is wave-uniform, so a row's byte offset lives in an
+// SGPR (the buffer instruction's soffset) and the three per-lane column offsets never change -- no
+// per-item address arithmetic -- and two of the four window rows (with their SWAR preparation) carry
+// over from one row pair to the next.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, int col_waves, int pairs_per_task, int n_tasks) {
+  __shared__ unsigned s_hist[MODE == WB_SIMPLE ? 768 : 1];
+  p.mode = MODE;  // the per-pixel switch in stat_add folds away
+  stat_hist_init(p, s_hist);
+  const int frame = blockIdx.y;
+  const unsigned step = (unsigned)p.src_step;
+  const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), step) + (unsigned)p.cols;
+  const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
+  const unsigned thresh255 = min(p.thresh255, 255u);
+  const int lane = threadIdx.x & 63;
+  const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+  StatAcc a = {};
+  if (task < n_tasks) {
+    const int cw = task % col_waves, range = task / col_waves;
+    const int grp = cw * 64 + lane;
+    const bool active = grp * 4 < p.cols;
+    const int x0 = active ? grp * 4 : 0;
+    const int off_c = x0, off_l = x0 >= 4 ? x0 - 4 : x0, off_r = x0 + 4 < p.cols ? x0 + 4 : x0;
+    const int n_pairs = p.rows >> 1;
+    const int pair_begin = range * pairs_per_task, pair_end = min(n_pairs, pair_begin + pairs_per_task);
+    struct RawRow {
+      uint32_t l, c, r;
+    };
+    auto fetch_row = [&](int y) {
+      const int row = (int)__umul24((unsigned)clampi(y, 0, p.rows - 1), step);  // wave-uniform: scalar
+      return RawRow{__builtin_amdgcn_raw_buffer_load_b32(src, off_l, row, 0), __builtin_amdgcn_raw_buffer_load_b32(src, off_c, row, 0),
+                    __builtin_amdgcn_raw_buffer_load_b32(src, off_r, row, 0)};
+    };
+    auto prep = [&](const RawRow& w) { return prep_row(w.l, w.c, w.r); };
+    auto consume = [&](const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3, int y0) {
+      Planar rowpx[2];
+      debayer_rows_any(r0, r1, r2, r3, p.bayer_ry, p.bayer_rx, rowpx);
+      debayer_fix_edges(y0, x0, p.rows, p.cols, rowpx);
+      if (!active) return;
+#pragma unroll
+      for (int ly = 0; ly < 2; ly++) {
+        if (MODE == WB_Q8) {
+          grayworld_add_swar(rowpx[ly], thresh255, a);
+          continue;
+        }
+#pragma unroll
+        for (int lx = 0; lx < 4; lx++)
+          stat_add(p, (int)((rowpx[ly].b >> (8 * lx)) & 0xFFu), (int)((rowpx[ly].g >> (8 * lx)) & 0xFFu),
+                   (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a, s_hist);
+      }
+    };
+    // two row pairs per iteration so the carried rows change roles without register moves; the two
+    // rows of the next pair are in flight while the current pair is reduced
+    int y0 = pair_begin * 2;
+    RowPrep ra = prep(fetch_row(y0 - 1)), rb = prep(fetch_row(y0));
+    RawRow n0 = fetch_row(y0 + 1), n1 = fetch_row(y0 + 2);
+    for (int pair = pair_begin; pair < pair_end; pair += 2, y0 += 4) {
+      const RowPrep rc = prep(n0), rd = prep(n1);
+      n0 = fetch_row(y0 + 3);
+      n1 = fetch_row(y0 + 4);
+      consume(ra, rb, rc, rd, y0);
+      if (pair + 1 >= pair_end) break;
+      ra = prep(n0);
+      rb = prep(n1);
+      n0 = fetch_row(y0 + 5);
+      n1 = fetch_row(y0 + 6);
+      consume(rc, rd, ra, rb, y0 + 2);
+    }
+  }
+  stat_flush(p, a, p.stats + frame, s_hist, frame);
+}
+
+// colour input (bgr8 / rgb8), 4 px per lane
+__global__ __launch_bounds__(kBlock) void stats_color_kernel(StatsParams p, ItemMap im, int items_per_frame) {
+  __shared__ unsigned s_hist[768];
+  stat_hist_init(p, s_hist);
+  const int frame = blockIdx.y;
+  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  const bool rgb = p.src_kind == SRC_RGB;
+  StatAcc a = {};
+  for (int item = blockIdx.x * kBlock + threadIdx.x; item < items_per_frame; item += gridDim.x * kBlock) {
+    int y, grp;
+    im.split(item, y, grp);
+    const uint3 in = *reinterpret_cast<const uint3*>(src + (__umul24((unsigned)y, (unsigned)p.src_step) + (unsigned)grp * 12u));
+    int q[4][3];
+    unpack12(in, rgb, q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) stat_add(p, q[k][0], q[k][1], q[k][2], a, s_hist);
+  }
+  stat_flush(p, a, p.stats + frame, s_hist, frame);
+}
+
+__global__ __launch_bounds__(kBlock) void stats_generic_kernel(StatsParams p) {
+  __shared__ unsigned s_hist[768];
+  stat_hist_init(p, s_hist);
+  const int frame = blockIdx.y;
+  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
+  const long long npix = (long long)p.rows * p.cols;
+  StatAcc a = {};
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
+    int y = (int)(i / p.cols), x = (int)(i - (long long)y * p.cols);
+    int b, g, r;
+    fetch_src(s, y, x, b, g, r);
+    stat_add(p, b, g, r, a, s_hist);
+  }
+  stat_flush(p, a, p.stats + frame, s_hist, frame);
+}
+
+// ------------------------------------------------------------------------------------------------
+// white-balance finalisation: statistics -> per-frame gains, on the device (no host round trip)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void solve2(float m00, float m01, float m10, float m11, float g0, float g1, float& o0, float& o1) {
+  // Eigen::Matrix2f::inverse() * vec (white_balance.cpp:104-115)
+  float det = m00 * m11 - m01 * m10;
+  float invdet = 1.0f / det;
+  float i00 = m11 * invdet, i01 = -m01 * invdet, i10 = -m10 * invdet, i11 = m00 * invdet;
+  o0 = i00 * g0 + i01 * g1;
+  o1 = i10 * g0 + i11 * g1;
+}
+
+__global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* st,
+                                   const DevTables* tabs, FrameWb* out, int n_frames, const unsigned* simple_hist,
+                                   float simple_p, int simple_total) {
+  if (mode == WB_FLOAT) {
+    // ccc: temporal filter is sequential over the frames of the stream
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    CccState s = *st;
+    for (int f = 0; f < n_frames; f++) {
+      s.uv_x = ccc_argmax[2 * f];
+      s.uv_y = ccc_argmax[2 * f + 1];
+      FrameWb w = {};
+      w.uv_raw[0] = s.uv_x;
+      w.uv_raw[1] = s.uv_y;
+      if (s.temporal) {
+        if (s.first_frame) {
+          s.first_frame = 0;
+          s.st_x = (float)s.uv_x;
+          s.st_y = (float)s.uv_y;
+        } else {
+          // cv::KalmanFilter(2,2,0) predict + correct with A = I, Q = I, H = h I, R = r I
+          float xs[2] = {s.st_x, s.st_y}, ps[2] = {s.p_x, s.p_y};
+          int z[2] = {s.uv_x, s.uv_y}, o[2];
+          for (int a = 0; a < 2; a++) {
+            float x_pre = xs[a];
+            float p_pre = ps[a] + 1.0f;
+            float t2 = s.kf_h * p_pre;
+            float t3 = t2 * s.kf_h + s.kf_r;
+            float k = t2 / t3;
+            float innov = (float)z[a] - s.kf_h * x_pre;
+            xs[a] = x_pre + k * innov;
+            ps[a] = p_pre - k * t2;
+            o[a] = (int)xs[a];
+          }
+          s.st_x = xs[0];
+          s.st_y = xs[1];
+          s.p_x = ps[0];
+          s.p_y = ps[1];
+          s.uv_x = o[0];
+          s.uv_y = o[1];
+        }
+      }
+      // computeGains (:342-381) with exp(-L) taken from the host-built table
+      int ux = clampi(s.uv_x, 0, 255), uy = clampi(s.uv_y, 0, 255);
+      float gain_r = 1.0f / tabs->exp_neg_tab[ux];
+      float gain_g = 1.0f;
+      float gain_b = 1.0f / tabs->exp_neg_tab[uy];
+      float factor = fminf(fminf(gain_r, gain_g), gain_b);
+      gain_r /= factor;
+      gain_g /= factor;
+      gain_b /= factor;
+      w.fg[0] = gain_b;
+      w.fg[1] = gain_g;
+      w.fg[2] = gain_r;
+      w.uv[0] = s.uv_x;
+      w.uv[1] = s.uv_y;
+      out[f] = w;
+    }
+    *st = s;
+    return;
+  }
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  FrameWb w = {};
+  if (mode == WB_SIMPLE) {
+    // cv::xphoto::SimpleWB (simple_color_balance.cpp balanceWhiteSimple<uchar>), restated literally:
+    // two-level tree of 16-bin histograms whose second level of bin 0 aliases the first level
+    const unsigned* h3 = simple_hist + (size_t)f * 768;
+    for (int c = 0; c < 3; c++) {
+      const unsigned* hist256 = h3 + c * 256;
+      int hist[256];
+      for (int i = 0; i < 256; i++) hist[i] = 0;
+      for (int v = 0; v < 256; v++) {
+        const int cnt = (int)hist256[v];
+        if (!cnt) continue;
+        int pos = 0;
+        float minValue = 0.f - 0.5f;
+        float interval = (255.5f - minValue) / 16;
+        for (int j = 0; j < 2; ++j) {
+          const int currentBin = (int)(((float)v - minValue + 1e-4f) / interval);
+          hist[pos + currentBin] += cnt;
+          pos = (pos + currentBin) * 16;
+          minValue = minValue + currentBin * interval;
+          interval /= 16;
+        }
+      }
+      const float s1 = simple_p, s2 = simple_p;
+      int p1 = 0, p2 = 15, n1 = 0, n2 = simple_total;
+      float minValue = 0.f - 0.5f, maxValue = 255.f + 0.5f;
+      float interval = (maxValue - minValue) / 16.0f;
+      for (int j = 0; j < 2; ++j) {
+        while (p1 < 255 && (float)(n1 + hist[p1]) < s1 * (float)simple_total / 100.0f) {
+          n1 += hist[p1++];
+          minValue += interval;
+        }
+        p1 *= 16;
+        while (p2 > 0 && (float)(n2 - hist[p2]) > (100.0f - s2) * (float)simple_total / 100.0f) {
+          n2 -= hist[p2--];
+          maxValue -= interval;
+        }
+        p2 = (p2 + 1) * 16 - 1;
+        interval /= 16;
+        if (p1 > 255) p1 = 255;
+        if (p2 > 255) p2 = 255;
+      }
+      const double d = (double)(maxValue - minValue);
+      const double inv = 1.0 / d;
+      w.fg[c] = (float)((1.0 * 255.0) * inv);
+      w.pca[c] = (float)(((-(double)minValue) * 255.0) * inv + 0.0);
+    }
+    out[f] = w;
+    return;
+  }
+  const FrameStats& fs = stats[f];
+  if (mode == WB_Q8) {
+    // GrayworldWBImpl::balanceWhite + applyChannelGains
+    double sb = (double)fs.sum[0], sg = (double)fs.sum[1], sr = (double)fs.sum[2];
+    double max_sum = fmax(sb, fmax(sr, sg));
+    float gb = sb < 0.1 ? 0.f : (float)(max_sum / sb);
+    float gg = sg < 0.1 ? 0.f : (float)(max_sum / sg);
+    float gr = sr < 0.1 ? 0.f : (float)(max_sum / sr);
+    float gmax = fmaxf(gb, fmaxf(gg, gr));
+    if (gmax > 0) {
+      gb /= gmax;
+      gg /= gmax;
+      gr /= gmax;
+    }
+    w.q8[0] = (int)__builtin_rintf(gb * 256.f);
+    w.q8[1] = (int)__builtin_rintf(gg * 256.f);
+    w.q8[2] = (int)__builtin_rintf(gr * 256.f);
+    w.fg[0] = gb;
+    w.fg[1] = gg;
+    w.fg[2] = gr;
+  } else if (mode == WB_PCA) {
+    double s_b = (double)fs.sum[0], s_b2 = (double)fs.sum[1], s_r = (double)fs.sum[2], s_r2 = (double)fs.sum[3],
+           s_g = (double)fs.sum[4];
+    float mb = (float)fs.mx[0], mr = (float)fs.mx[1], mg = (float)fs.mx[2];
+    float mb2 = mb * mb, mr2 = mr * mr;
+    solve2((float)s_b2, (float)s_b, mb2, mb, (float)s_g, mg, w.pca[0], w.pca[1]);
+    solve2((float)s_r2, (float)s_r, mr2, mr, (float)s_g, mg, w.pca[2], w.pca[3]);
+  }
+  out[f] = w;
+}
+
+}  // namespace
+
+void launch_stats(const StatsParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  if (bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = (p.rows / 2) * (p.cols / 4);
+    // keep >= 1 block per 2^20 items so the 32-bit per-thread partial sums cannot overflow
+    // wave tasks: 64 groups wide x pairs_per_task row pairs.  The wave total of the largest statistic
+    // (pca: sum of squares) is 64 lanes * 8 px * 255^2 * pairs_per_task: 128 pairs keep it below 2^32
+    const int groups = p.cols / 4, n_pairs = p.rows / 2;
+    const int col_waves = (groups + 63) / 64;
+    // per frame: 512 wave tasks when the batch fills the chip anyway, at most 1024 for a single frame (more
+    // tasks only queue up on the three 64-bit atomics every workgroup ends with: 22 -> 12.6 us for one frame)
+    const int budget = tune_env("RIP_STATS_BLOCKS", 2048) * 4;
+    const int target_tasks = std::max(8, std::min(budget / 8, budget / std::max(1, std::min(p.n_frames, 16))));
+    int pairs_per_task = std::max(2, (int)(((long long)col_waves * n_pairs + target_tasks - 1) / target_tasks));
+    pairs_per_task = std::min((pairs_per_task + 1) & ~1, 128);  // even: the kernel consumes two pairs per iteration
+    const int n_tasks = col_waves * ((n_pairs + pairs_per_task - 1) / pairs_per_task);
+    const dim3 grid((n_tasks + kBlock / 64 - 1) / (kBlock / 64), p.n_frames);
+    (void)items;
+    (void)im;
+    if (p.mode == WB_Q8)
+      hipLaunchKernelGGL(stats_fast_kernel<WB_Q8>, grid, dim3(kBlock), 0, stream, p, col_waves, pairs_per_task, n_tasks);
+    else if (p.mode == WB_SIMPLE)
+      hipLaunchKernelGGL(stats_fast_kernel<WB_SIMPLE>, grid, dim3(kBlock), 0, stream, p, col_waves, pairs_per_task, n_tasks);
+    else
+      hipLaunchKernelGGL(stats_fast_kernel<WB_PCA>, grid, dim3(kBlock), 0, stream, p, col_waves, pairs_per_task, n_tasks);
+    return;
+  }
+  if (color_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = p.rows * (p.cols / 4);
+    int per_frame = grid_blocks_for(items, std::max(8, 2048 / std::max(1, std::min(p.n_frames, 16))));
+    per_frame = std::max(per_frame, (int)((items + (1 << 20) - 1) >> 20));
+    hipLaunchKernelGGL(stats_color_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
+    return;
+  }
+  long long npix = (long long)p.rows * p.cols;
+  int blocks = std::max(grid_blocks_for(npix, 1024), (int)((npix + (1 << 22) - 1) >> 22));
+  hipLaunchKernelGGL(stats_generic_kernel, dim3(blocks, p.n_frames), dim3(kBlock), 0, stream, p);
+}
+
+void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
+                        const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream, const unsigned* simple_hist,
+                        float simple_p, int simple_total) {
+  if (n_frames <= 0) return;
+  if (mode == WB_FLOAT) {
+    hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, stream, mode, stats, ccc_argmax, ccc_state, tabs, out, n_frames,
+                       simple_hist, simple_p, simple_total);
+  } else {
+    hipLaunchKernelGGL(wb_finalize_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, mode, stats, ccc_argmax,
+                       ccc_state, tabs, out, n_frames, simple_hist, simple_p, simple_total);
+  }
+}
+
+}  // namespace rip

@@ -2,7 +2,7 @@
 raw_image_pipeline_python.cpp:14-74: class ``RawImagePipeline``, 2 constructors, snake_case methods)
 implemented over the C-ABI of ``librip_hip.so`` (include/rip.h) with ctypes.
 
-All per-frame work runs in the HIP kernels of csrc/rip_kernels.hip; this module only marshals
+All per-frame work runs in the HIP kernels of csrc/rip_{chain,stats,ccc,remap}.hip; this module only marshals
 numpy / torch buffers.  It never falls back to a CPU implementation: a missing library or a
 missing GPU raises.
 """

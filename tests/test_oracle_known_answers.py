@@ -376,7 +376,7 @@ def test_pipeline_reference_schedule_gives_same_pixels(oracle):
 
 def test_lab_ab_never_saturate(oracle):
     """RGB2Lab_b saturates a and b to [0, 255]; over all 2^24 BGR inputs the unsaturated values stay inside
-    [42, 226] and [20, 223], so the device kernel drops the clamp (rip_kernels.hip apply_vignette) and folds
+    [42, 226] and [20, 223], so the device kernel drops the clamp (rip_device.hpp apply_vignette) and folds
     the float-to-int bias into the next multiply-add.  L covers exactly [0, 255]."""
     g = oracle.table("srgb_gamma").astype(np.int64)
     cb = oracle.table("cbrt").astype(np.int64)
