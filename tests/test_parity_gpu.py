@@ -341,6 +341,37 @@ def test_ccc_white_balance_sequence_config3(gpu_pipe, oracle):
     assert len(set(seen[n:])) > 1, "H = I: the estimate must follow the drifting tint"
 
 
+def test_config3_full_size_1920x1200_ccc_batch(gpu_pipe, oracle):
+    """BASELINE configs[2] at its own size: 1920x1200 gbrg8, ccc with the Kalman filter following a drifting tint,
+    HSV enhancer; four frames as ONE resident batch (the estimator's sequential Kalman step runs on the device)."""
+    import torch
+    w, h, n = 1920, 1200, 4
+    filt, bias = synth.ccc_model()
+    gpu_pipe.set_ccc_model(filt, bias)
+    occ = oracle.CCC(filt, bias)
+    occ.set_kalman_model(1.0, 10.0)
+    gpu_pipe.set_ccc_kalman_model(1.0, 10.0)
+    c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=True, ce=True, ce_sat=1.2)
+    configure(gpu_pipe, c)
+    gpu_pipe.reset_white_balance_temporal_consistency()
+    frames = np.stack([synth.gen_frame(w, h, "bayer_gbrg8", seed=3000 + i, kind="scene", tint=(0.70 + 0.03 * i, 1.0, 0.55))
+                       for i in range(n)])
+    out = gpu_pipe.apply_device(torch.from_numpy(frames).cuda(), "bayer_gbrg8")
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i in range(n):
+        ref, _ = oracle_run(oracle, c, frames[i], "bayer_gbrg8", ccc=occ)
+        assert_images_equal(out[i], ref, "config3 frame %d" % i, TOL_DECLARED)
+
+
+def test_config5_full_size_3840x2160_debayer_undistort(gpu_pipe, oracle):
+    """BASELINE configs[4] at its own size: 3840x2160 rggb8, debayer + fisheye undistortion."""
+    w, h = 3840, 2160
+    c = cfg(undistort=True, cam=synth.camera_model(w, h))
+    frame = synth.gen_frame(w, h, "bayer_rggb8", seed=5, kind="scene")
+    run_both(gpu_pipe, oracle, c, frame, "bayer_rggb8", TOL_INTERP, what="config5 3840x2160")
+
+
 def test_error_behaviour(gpu_pipe):
     frame = synth.gen_frame(64, 48)
     configure(gpu_pipe, cfg())
