@@ -238,7 +238,9 @@ def main():
 
     # roofline of the dominant kernel class, from the HIP events recorded around its launches
     px = width * height
-    dom = max(prof, key=lambda k: prof[k][0])
+    # the streaming class with the largest total; the ccc estimator (O(1) bytes per frame) is listed in
+    # kernel_ms_per_step but has no HBM roofline
+    dom = max((k for k in prof if bytes_per_px(k, args.batch) > 0), key=lambda k: prof[k][0])
     dom_ms, dom_n = prof[dom]
     out_px = orows * ocols if dom == "remap" else px
     per_launch_bytes = bytes_per_px(dom, args.batch) * out_px * args.batch

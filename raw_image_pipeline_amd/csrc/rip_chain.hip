@@ -373,7 +373,13 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     // persistent grid: at most 256 CUs x 8 workgroups, a multiple of 8 (one share per XCD)
     const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
-    const int groups = std::max(1, std::min(p.n_frames, cap / blocks));
+    // blockIdx.y splits the batch: at most 16 frames per item visit (RIP_CHAIN_FRAMES).  2448 chunks on 2048
+    // persistent workgroups would leave most of the chip idle while a fifth of them does a second chunk; four
+    // times as many, shorter units let the dispatcher even that out (config2: 0.80 -> 0.75 ms) and 16 frames
+    // still amortise the per-item setup (FP64 vignetting mask, addresses).
+    const int frames_per_visit = std::max(1, tune_env("RIP_CHAIN_FRAMES", 16));
+    int groups = std::max(cap / blocks, (p.n_frames + frames_per_visit - 1) / frames_per_visit);
+    groups = std::max(1, std::min(p.n_frames, groups));
     dim3 grid(blocks, groups);
     switch (p.stage_bits & 15) {
 #define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream); break;
