@@ -19,7 +19,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLASS = {"stats": "stats_", "chain": "chain_", "remap": "remap_", "ccc": "ccc_"}
-FETCH_FACTOR = {"stats": 1.0, "chain": 1.0, "remap": 2.0, "ccc": 1.0}
 
 
 def run_pass(out_dir, name, counters, workload):
@@ -41,7 +40,8 @@ def main():
     result, lines = {}, []
     for wl in workloads:
         per = {}
-        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+                               ("rdsplit", ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"])):
             for row in run_pass(out_dir, name, counters, wl):
                 kname = row["Kernel_Name"]
                 cls = next((c for c, pat in CLASS.items() if pat in kname), None)
@@ -56,18 +56,28 @@ def main():
             total = 0.0
             for short, d in sorted(kernels.items()):
                 fetch, write = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
-                factor = 2.0 if short in ("remap_tiled_kernel", "remap_ring_kernel") else 1.0  # 16 B/lane loads: MI355X_MICROARCH.md, HBM section
+                # FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every read request of these kernels is 128 B wide (the size-split
+                # counters below; tools/probes/fetch_calib_probe.hip reads 2147 MB and reports 1074 MB for 4 B/lane and
+                # 16 B/lane loads alike): x2, the gfx950 correction of MI355X_MICROARCH.md's HBM section
+                factor = 2.0
                 fb, wb = med(fetch) * 1024 * factor, med(write) * 1024
+                exact = 32 * med(d.get("TCC_EA0_RDREQ_32B_sum", [])) + 64 * med(d.get("TCC_EA0_RDREQ_64B_sum", [])) + \
+                    128 * med(d.get("TCC_EA0_RDREQ_128B_sum", []))
                 total += fb + wb
-                lines.append("%-8s %-6s %-22s launches=%-3d FETCH_SIZE(med)=%.0f KiB x%.0f -> %.1f MB   WRITE_SIZE(med)=%.0f KiB -> %.1f MB"
-                             % (wl, cls, short, len(fetch), med(fetch), factor, fb / 1e6, med(write), wb / 1e6))
+                lines.append("%-8s %-6s %-22s launches=%-3d FETCH_SIZE(med)=%.0f KiB x%.0f -> %.1f MB (32/64/128-B request counters: %.1f MB)   "
+                             "WRITE_SIZE(med)=%.0f KiB -> %.1f MB"
+                             % (wl, cls, short, len(fetch), med(fetch), factor, fb / 1e6, exact / 1e6, med(write), wb / 1e6))
             result[wl][cls] = int(total)
             lines.append("%-8s %-6s total %.1f MB per step (one launch of each kernel of the class)" % (wl, cls, total / 1e6))
+    sys.path.insert(0, ROOT)
+    import bench  # the default --batch of the command that was profiled
+    sys.argv = sys.argv[:1]
+    result["frames_per_launch"] = bench.parse_args().batch
     with open(os.path.join(out_dir, "pmc_traffic.json"), "w") as f:
         json.dump(result, f, indent=1, sort_keys=True)
     with open(os.path.join(out_dir, "pmc_summary.txt"), "w") as f:
         f.write("# HBM traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes) of\n"
-                "# `bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-probe --workload <wl>` (64 frames per launch)\n")
+                "# `bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-probe --workload <wl>` (%d frames per launch)\n" % result["frames_per_launch"])
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
