@@ -16,6 +16,60 @@ __device__ __forceinline__ void fetch_flipped(const SrcView& s, int angle, int y
   fetch_src(s, ys, xs, b, g, r);
 }
 
+// Demosaic of the 2x2 block whose top-left pixel is (y, x), all four pixels interior (no border rule):
+// the 4x4 raw window around it is read with two aligned dwords per row instead of nine byte loads per
+// pixel.  Every 2x2 block holds one site of each kind; out[i * 2 + j] = pixel (y + i, x + j) as b, g, r.
+__device__ __forceinline__ void debayer_block2x2(const SrcView& s, int y, int x, int (&out)[4][3]) {
+  int v[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const unsigned off = __umul24((unsigned)(y - 1 + r), (unsigned)s.step) + (unsigned)(x - 1);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(s.base + (off & ~3u));
+    const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], off & 3u);
+#pragma unroll
+    for (int c = 0; c < 4; c++) v[r][c] = (int)((w >> (8 * c)) & 0xFFu);
+  }
+  const int py = (y - s.ry) & 1, px = (x - s.rx) & 1;  // parity of the block's top-left pixel: (0,0) = R site
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int cy = 1 + i, cx = 1 + j, dy = py ^ i, dx = px ^ j;
+      const int c = v[cy][cx];
+      const int h = (v[cy][cx - 1] + v[cy][cx + 1] + 1) >> 1, vv = (v[cy - 1][cx] + v[cy + 1][cx] + 1) >> 1;
+      const int x4 = (v[cy][cx - 1] + v[cy][cx + 1] + v[cy - 1][cx] + v[cy + 1][cx] + 2) >> 2;
+      const int d4 = (v[cy - 1][cx - 1] + v[cy - 1][cx + 1] + v[cy + 1][cx - 1] + v[cy + 1][cx + 1] + 2) >> 2;
+      int b, g, r;
+      if (dy != dx) {  // green site
+        g = c;
+        r = dy == 0 ? h : vv;
+        b = dy == 0 ? vv : h;
+      } else {
+        g = x4;
+        r = dy == 0 ? c : d4;
+        b = dy == 0 ? d4 : c;
+      }
+      out[i * 2 + j][0] = b;
+      out[i * 2 + j][1] = g;
+      out[i * 2 + j][2] = r;
+    }
+}
+
+// the 2x2 block of post-flip pixels at (y, x): fast window path for unflipped Bayer frames, else per pixel
+__device__ __forceinline__ void fetch_block2x2(const SrcView& s, int angle, int y, int x, int y1, int x1, int (&out)[4][3]) {
+  const bool fast = s.kind == SRC_BAYER && angle == 0 && y1 == y + 1 && x1 == x + 1 && y >= 1 && y1 <= s.rows - 2 && x >= 1 &&
+                    x1 <= s.cols - 2 && (unsigned)(x + 6) < (unsigned)s.step && (reinterpret_cast<uintptr_t>(s.base) & 3u) == 0 &&
+                    (s.step & 3u) == 0 && (unsigned long long)s.step * (unsigned long long)s.rows < (1ull << 32) && s.step < (1u << 24);
+  if (fast) {
+    debayer_block2x2(s, y, x, out);
+    return;
+  }
+  fetch_flipped(s, angle, y, x, out[0][0], out[0][1], out[0][2]);
+  fetch_flipped(s, angle, y, x1, out[1][0], out[1][1], out[1][2]);
+  fetch_flipped(s, angle, y1, x, out[2][0], out[2][1], out[2][2]);
+  fetch_flipped(s, angle, y1, x1, out[3][0], out[3][1], out[3][2]);
+}
+
 __global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
   const int frame = blockIdx.y;
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -23,19 +77,11 @@ __global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
   const int dy = i / 360, dx = i - dy * 360;
   SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
   int sm[3];
+  int t[4][3];  // taps (y0,x0) (y0,x1) (y1,x0) (y1,x1)
   if (p.geom.area_fast) {
-    int acc[3] = {2, 2, 2};
+    fetch_block2x2(s, p.flip_angle, 2 * dy, 2 * dx, 2 * dy + 1, 2 * dx + 1, t);
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      int b, g, r;
-      fetch_flipped(s, p.flip_angle, 2 * dy + (t >> 1), 2 * dx + (t & 1), b, g, r);
-      acc[0] += b;
-      acc[1] += g;
-      acc[2] += r;
-    }
-    sm[0] = acc[0] >> 2;
-    sm[1] = acc[1] >> 2;
-    sm[2] = acc[2] >> 2;
+    for (int c = 0; c < 3; c++) sm[c] = (t[0][c] + t[1][c] + t[2][c] + t[3][c] + 2) >> 2;
   } else {
     // cv::resize INTER_LINEAR, 8U: Q11 coefficients, two-pass integer arithmetic
     const int sx = p.geom.xofs[dx];
@@ -43,15 +89,11 @@ __global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
     const int a0 = p.geom.ialpha[dx * 2], a1 = p.geom.ialpha[dx * 2 + 1];
     const int y0 = p.geom.yofs[dy * 2], y1 = p.geom.yofs[dy * 2 + 1];
     const int b0 = p.geom.ibeta[dy * 2], b1 = p.geom.ibeta[dy * 2 + 1];
-    int p00[3], p01[3], p10[3], p11[3];
-    fetch_flipped(s, p.flip_angle, y0, sx, p00[0], p00[1], p00[2]);
-    fetch_flipped(s, p.flip_angle, y0, sx1, p01[0], p01[1], p01[2]);
-    fetch_flipped(s, p.flip_angle, y1, sx, p10[0], p10[1], p10[2]);
-    fetch_flipped(s, p.flip_angle, y1, sx1, p11[0], p11[1], p11[2]);
+    fetch_block2x2(s, p.flip_angle, y0, sx, y1, sx1, t);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      int r0 = p00[c] * a0 + p01[c] * a1;
-      int r1 = p10[c] * a0 + p11[c] * a1;
+      int r0 = t[0][c] * a0 + t[1][c] * a1;
+      int r1 = t[2][c] * a0 + t[3][c] * a1;
       sm[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
     }
   }
