@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librip_hip.so")
 SOURCES = ["rip_chain.hip", "rip_stats.hip", "rip_ccc.hip", "rip_remap.hip", "rip_host.cpp", "rip_api.cpp"]  # compiled in parallel
-HEADERS = ["rip_kernels.hpp", "rip_device.hpp", "rip_host.hpp", os.path.join("..", "..", "include", "rip.h")]
+HEADERS = ["rip_kernels.hpp", "rip_device.hpp", "rip_tile.hpp", "rip_host.hpp", os.path.join("..", "..", "include", "rip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
 
@@ -38,7 +38,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for s in SOURCES:
         obj = os.path.join(HERE, "build", os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [hipcc()] + FLAGS + os.environ.get("RIP_EXTRA_FLAGS", "").split() + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -2,6 +2,7 @@
 // eight modules), the YAML-subset reader for the three config files, and the builders of the
 // constant tables / undistortion maps the HIP kernels consume.  No device code here.
 #pragma once
+#include "rip_tile.hpp"
 
 #include <cstdint>
 #include <map>
@@ -139,7 +140,7 @@ void fisheye_init_undistort_rectify_map(const double K[9], const double D[4], co
 // outside the source (border constant 0); kRemapBorder: some taps fall outside -- the kernel
 // takes the per-tap path on the float map for it.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRemapTileW = 64, kRemapTileH = 16;
+// kRemapTileW, kRemapTileH: rip_tile.hpp
 constexpr uint32_t kRemapOutside = 0xFFFFFFFFu, kRemapBorder = 0xFFFFFFFEu;
 struct RemapTile {
   int x0, y0, w, h;  // source rectangle in pixels (w == 0: no interior pixel in this tile)

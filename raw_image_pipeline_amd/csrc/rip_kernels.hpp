@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "rip_tile.hpp"
+
 #include <cstddef>
 #include <cstdint>
 

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void remap_border_kernel(RemapTiledParams p
 // PRE: staging slots (16-byte chunks) per lane held in registers while the previous frame is gathered;
 // 0 = no software pipeline (one LDS buffer, any rectangle size)
 template <int PRE>
-__global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p) {
+__global__ __launch_bounds__(kRemapTileThreads) void remap_tiled_kernel(RemapTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int kPre = PRE > 0 ? PRE : 1;
   const RemapParams& b = p.base;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
   const int per_xcd = (ntiles + 7) / 8;
   const int xcd = blockIdx.x & 7;
   const int tid = threadIdx.x;
-  const int lrow = tid >> 4, lgrp = tid & 15;
+  const int lrow = tid / kRemapGroupsPerRow, lgrp = tid % kRemapGroupsPerRow;
   const unsigned step = (unsigned)b.src_step;
   const int f_per_group = (b.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
   const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(b.n_frames, f_begin + f_per_group);
@@ -172,9 +172,9 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
     if (tile >= ntiles) break;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const RemapTileDesc d = p.tiles[tile];
-    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * 1024)[tid];
+    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * kRemapTilePx)[tid];
     const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
-    const int yd = ty * 16 + lrow, xd = tx * 64 + lgrp * 4;
+    const int yd = ty * kRemapTileH + lrow, xd = tx * kRemapTileW + lgrp * 4;
     const bool in_image = yd < b.drows && xd < b.dcols;
     const unsigned xbyte0 = (unsigned)d.x0 * 3u;
     const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
       unsigned goff[kPre], loff[kPre];
 #pragma unroll
       for (int j = 0; j < kPre; j++) {
-        const unsigned i = (unsigned)tid + (unsigned)j * kBlock;
+        const unsigned i = (unsigned)tid + (unsigned)j * kRemapTileThreads;
         int r, c;
         cm.split((int)i, r, c);
         goff[j] = i < total ? __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFFFu;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void remap_tiled_kernel(RemapTiledParams p)
     } else {
       for (int f = f_begin; f < f_end; f++) {
         const RemapSrc s = remap_src(b, f);
-        for (unsigned i = tid; i < total; i += kBlock) {
+        for (unsigned i = tid; i < total; i += kRemapTileThreads) {
           int r, c;
           cm.split((int)i, r, c);
           const unsigned off = __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4);
@@ -309,15 +309,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int PRE>
-__global__ __launch_bounds__(kBlock) void remap_ring_kernel(RemapTiledParams p) {
+__global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  constexpr unsigned kStage = (unsigned)PRE * kBlock * 16u;  // bytes per stage
+  constexpr unsigned kStage = (unsigned)PRE * kRemapTileThreads * 16u;  // bytes per stage
   const RemapParams& b = p.base;
   const int ntiles = p.tiles_x * p.tiles_y;
   const int per_xcd = (ntiles + 7) / 8;
   const int xcd = blockIdx.x & 7;
   const int tid = threadIdx.x;
-  const int lrow = tid >> 4, lgrp = tid & 15;
+  const int lrow = tid / kRemapGroupsPerRow, lgrp = tid % kRemapGroupsPerRow;
   const unsigned step = (unsigned)b.src_step;
   const int f_per_group = (b.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
   const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(b.n_frames, f_begin + f_per_group);
@@ -331,9 +331,9 @@ __global__ __launch_bounds__(kBlock) void remap_ring_kernel(RemapTiledParams p) 
     if (tile >= ntiles) break;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const RemapTileDesc d = p.tiles[tile];
-    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * 1024)[tid];
+    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * kRemapTilePx)[tid];
     const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
-    const int yd = ty * 16 + lrow, xd = tx * 64 + lgrp * 4;
+    const int yd = ty * kRemapTileH + lrow, xd = tx * kRemapTileW + lgrp * 4;
     const bool in_image = yd < b.drows && xd < b.dcols;
     const unsigned xbyte0 = (unsigned)d.x0 * 3u;
     const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void remap_ring_kernel(RemapTiledParams p) 
     unsigned goff[PRE];
 #pragma unroll
     for (int j = 0; j < PRE; j++) {
-      const unsigned i = (unsigned)tid + (unsigned)j * kBlock;
+      const unsigned i = (unsigned)tid + (unsigned)j * kRemapTileThreads;
       int r, c;
       cm.split((int)i, r, c);
       goff[j] = i < total ? __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFF0u;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void remap_ring_kernel(RemapTiledParams p) 
       const __amdgpu_buffer_rsrc_t rsrc = frame_rsrc(s.frame, s.readable);
       const unsigned stage = lds0 + (unsigned)slot * kStage;
 #pragma unroll
-      for (int j = 0; j < PRE; j++) lds_dma16(rsrc, goff[j], stage + ((wave_chunk0 + (unsigned)j * kBlock) << 4));
+      for (int j = 0; j < PRE; j++) lds_dma16(rsrc, goff[j], stage + ((wave_chunk0 + (unsigned)j * kRemapTileThreads) << 4));
     };
     auto gather_store = [&](const uint8_t* buf, int f) {
       if (!in_image) return;
@@ -455,7 +455,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
                   (reinterpret_cast<uintptr_t>(p.words) & 15u) == 0 && b.src_step < (1u << 24) && b.rows < (1 << 23) &&
                   (unsigned long long)b.src_step * (unsigned long long)b.rows < (1ull << 32) && b.dst_step < (1u << 24) &&
                   (unsigned long long)b.dst_step * (unsigned long long)b.drows < (1ull << 32) && p.lds_bytes <= 64u * 1024u &&
-                  p.tiles_x * 64 >= b.dcols && p.tiles_y * 16 >= b.drows && b.drows <= 65535 && b.dcols <= 65535;
+                  p.tiles_x * kRemapTileW >= b.dcols && p.tiles_y * kRemapTileH >= b.drows && b.drows <= 65535 && b.dcols <= 65535;
   if (!ok) return false;
   const int ntiles = p.tiles_x * p.tiles_y;
   // persistent workgroups, a multiple of 8 (one share of the tile range per XCD); LDS bounds residency
@@ -466,10 +466,10 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
   // measured on config2 (sweeps in DESIGN.md): 3 stages (two frames ahead) with 4 workgroups per CU; more resident
   // workgroups fetch more (the source rectangles of neighbouring tiles stop meeting in L2) and run slower
   const int stages_env = tune_env("RIP_REMAP_STAGES", 3);
-  if (ring_env && chunks <= 4u * kBlock) {
+  if (ring_env && chunks <= 4u * kRemapTileThreads) {
     // LDS-DMA ring: PRE chunks per lane and frame, `stages` buffers of PRE * 4 KiB
-    const int pre = chunks <= 1u * kBlock ? 1 : (chunks <= 2u * kBlock ? 2 : 4);
-    const unsigned stage_bytes = (unsigned)pre * kBlock * 16u;
+    const int pre = chunks <= 1u * kRemapTileThreads ? 1 : (chunks <= 2u * kRemapTileThreads ? 2 : 4);
+    const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
     q.stages = std::max(2, std::min(4, stages_env));
     const unsigned lds = (unsigned)q.stages * stage_bytes + 16u;  // the three-dword tap reads run up to 11 B past a row
     const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 6), (int)((160u * 1024u) / (lds + 256u))));
@@ -485,14 +485,14 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
     groups = std::max(1, std::min(b.n_frames, groups));
     const dim3 grid(blocks, groups);
     if (pre == 1)
-      hipLaunchKernelGGL(remap_ring_kernel<1>, grid, dim3(kBlock), lds, stream, q);
+      hipLaunchKernelGGL(remap_ring_kernel<1>, grid, dim3(kRemapTileThreads), lds, stream, q);
     else if (pre == 2)
-      hipLaunchKernelGGL(remap_ring_kernel<2>, grid, dim3(kBlock), lds, stream, q);
+      hipLaunchKernelGGL(remap_ring_kernel<2>, grid, dim3(kRemapTileThreads), lds, stream, q);
     else
-      hipLaunchKernelGGL(remap_ring_kernel<4>, grid, dim3(kBlock), lds, stream, q);
+      hipLaunchKernelGGL(remap_ring_kernel<4>, grid, dim3(kRemapTileThreads), lds, stream, q);
   } else {
-    // rectangles larger than 4 * kBlock chunks (strong local magnification) or RIP_REMAP_RING=0 (A/B runs)
-    int pre = !ring_env && b.n_frames >= 2 && chunks <= 2u * kBlock ? 2 : 0;
+    // rectangles larger than 4 * kRemapTileThreads chunks (strong local magnification) or RIP_REMAP_RING=0 (A/B runs)
+    int pre = !ring_env && b.n_frames >= 2 && chunks <= 2u * kRemapTileThreads ? 2 : 0;
     q.double_buffer = pre > 0 ? 1 : 0;
     const unsigned lds = (q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes) + 16u;
     const int per_cu = std::max(1, std::min(tune_env("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
@@ -501,12 +501,12 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
     const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too
     const dim3 grid(blocks, groups);
     if (pre == 2)
-      hipLaunchKernelGGL(remap_tiled_kernel<2>, grid, dim3(kBlock), lds, stream, q);
+      hipLaunchKernelGGL(remap_tiled_kernel<2>, grid, dim3(kRemapTileThreads), lds, stream, q);
     else
-      hipLaunchKernelGGL(remap_tiled_kernel<0>, grid, dim3(kBlock), lds, stream, q);
+      hipLaunchKernelGGL(remap_tiled_kernel<0>, grid, dim3(kRemapTileThreads), lds, stream, q);
   }
   if (q.n_border > 0)
-    hipLaunchKernelGGL(remap_border_kernel, dim3((q.n_border + kBlock - 1) / kBlock, b.n_frames), dim3(kBlock), 0, stream, q);
+    hipLaunchKernelGGL(remap_border_kernel, dim3((q.n_border + 255) / 256, b.n_frames), dim3(256), 0, stream, q);
   return true;
 }
 
