@@ -194,16 +194,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pipeline has no CPU execution path")
-    torch.cuda.set_device(local_rank)
+    # RIP_BENCH_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the multi-rank path on a 1-GPU box (ranks share
+    # the device); the driver's runs use one rank per GPU over RCCL
+    backend = os.environ.get("RIP_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from raw_image_pipeline_amd import RawImagePipeline
 
     dims = {"config2": (2448, 2048), "chain": (2448, 2048), "config3": (1920, 1200), "config5": (3840, 2160)}
     width, height = dims[args.workload]
-    pipe = RawImagePipeline(False, "", "", "", device=local_rank)
+    pipe = RawImagePipeline(False, "", "", "", device=device_index)
     pipe.set_stream(torch.cuda.current_stream())
     pattern, stages = configure(pipe, args.workload, width, height)
 
