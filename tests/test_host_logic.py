@@ -162,3 +162,31 @@ def test_remap_plan_words_reproduce_the_quantised_map(host_pipe, oracle):
     a = oracle.remap(img, mx, my)
     b = oracle.remap(img, (sxq / 32.0).astype(np.float32), (syq / 32.0).astype(np.float32))
     assert np.array_equal(a, b)
+
+
+REF_WB = "/root/reference/raw_image_pipeline_white_balance"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_WB + "/model/default.bin"), reason="reference tree not mounted (GPU box)")
+def test_reference_ccc_model_file_loads_and_balances_the_reference_sample_image(oracle):
+    """The reference's own model file (default.bin: int w, int h, float filter[w*h], float bias[w*h],
+    convolutional_color_constancy.cpp:116-130) goes through rip_load_ccc_model, and the oracle's estimator with that
+    model pulls the reference's sample image (data/alphasense.png, a greenish raw-looking frame) towards grey.
+    Runs only where the reference tree is mounted; nothing is copied from it."""
+    from PIL import Image
+    raw = np.fromfile(REF_WB + "/model/default.bin", dtype=np.uint8)
+    w, h = np.frombuffer(raw[:8].tobytes(), dtype=np.int32)
+    assert (w, h) == (256, 256) and raw.size == 8 + 2 * 4 * w * h
+    filt = np.frombuffer(raw[8:8 + 4 * w * h].tobytes(), dtype=np.float32).reshape(h, w)
+    bias = np.frombuffer(raw[8 + 4 * w * h:].tobytes(), dtype=np.float32).reshape(h, w)
+    assert np.isfinite(filt).all() and np.isfinite(bias).all() and filt.std() > 0
+    p = RawImagePipeline(False, device=-1)
+    p.load_ccc_model(REF_WB + "/model/default.bin")          # host-side parse + spectrum build
+    with pytest.raises(Exception):
+        p.load_ccc_model(REF_WB + "/model/missing.bin")
+    img = np.asarray(Image.open(REF_WB + "/data/alphasense.png").convert("RGB"))[..., ::-1].copy()  # BGR
+    ccc = oracle.CCC(filt, bias)
+    out, info, gains = ccc.balance(img)
+    assert all(np.isfinite(g) and 0.2 < g < 5.0 for g in gains), gains
+    spread = lambda im: np.ptp(im.reshape(-1, 3).mean(axis=0))
+    assert spread(out) < spread(img), (spread(img), spread(out), gains)  # channel means move together
