@@ -195,6 +195,7 @@ class CameraRig:
         self.streams = []
         self.devices = []
         self.hip_streams = []
+        self._pool = None
         for c, params in enumerate(camera_params):
             dev = c % n_devices
             with torch.cuda.device(dev):
@@ -205,10 +206,19 @@ class CameraRig:
             self.devices.append(dev)
             self.hip_streams.append(s)
 
-    def on_images(self, images, encodings, stamp=0.0):
-        """One frame per camera (the synchronised trigger of a multi-camera rig)."""
-        return [cam.on_image(img, enc, stamp=stamp, frame_id="cam%d" % c)
-                for c, (cam, img, enc) in enumerate(zip(self.streams, images, encodings))]
+    def on_images(self, images, encodings, stamp=0.0, parallel=True):
+        """One frame per camera (the synchronised trigger of a multi-camera rig).  With `parallel` every camera's
+        host -> device copy, kernels and device -> host copy run on its own thread and HIP stream (the C call
+        releases the GIL), so one camera's read-back overlaps the next one's upload and kernels: the host path is
+        PCIe-bound and the link is full duplex."""
+        jobs = list(enumerate(zip(self.streams, images, encodings)))
+        run = lambda job: job[1][0].on_image(job[1][1], job[1][2], stamp=stamp, frame_id="cam%d" % job[0])
+        if not parallel or len(jobs) < 2:
+            return [run(j) for j in jobs]
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self.streams), thread_name_prefix="rip-camera")
+        return list(self._pool.map(run, jobs))
 
     def process_resident(self, batches, encodings, outs=None):
         """Device-resident batches, one per camera, each on its owner's device and stream; asynchronous."""
