@@ -146,6 +146,9 @@ def cpu_baseline(width, height, pattern, seconds):
         O.pipeline(prm, frame, pattern)
 
     work()  # warm-up (page faults, table init)
+    t1 = time.perf_counter()
+    work()  # one frame on one otherwise idle core
+    single = 1.0 / (time.perf_counter() - t1)
     done = 0
     t0 = time.perf_counter()
     while True:
@@ -158,7 +161,7 @@ def cpu_baseline(width, height, pattern, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or done >= 64 * cores:
             break
-    return {"value": round(done / el, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(done / el, 3), "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_value": round(single, 3),
             "sample": "%d frames of the same %dx%d %s full chain, oracle in the reference-faithful schedule "
                       "(per-stage passes, 4 frame copies, mask rebuilt per frame), %d threads x 1 frame, %.1f s"
                       % (done, width, height, pattern, cores, el)}
@@ -275,7 +278,8 @@ def main():
         # what this box's HBM actually delivers to a plain streaming kernel, beside the 8 TB/s spec
         del out
         probe = hbm_probe(torch)
-        roofline["empirical"] = dict(probe, frac_of_copy=round(achieved / probe["copy_GBps"], 4) if probe["copy_GBps"] else None)
+        roofline["empirical"] = dict(probe, frac_of_copy=round(achieved / probe["copy_GBps"], 4) if probe["copy_GBps"] else None,
+                                     frac_of_read=round(achieved / probe["read_GBps"], 4) if probe["read_GBps"] else None)
     result = {
         "metric": "frames/sec at 2448x2048 bayer_rggb8 full chain; achieved HBM GB/s vs roofline",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
