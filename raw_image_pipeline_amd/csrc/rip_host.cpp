@@ -68,6 +68,48 @@ std::vector<std::string> split_flow(const std::string& body, int line_no) {
   return out;
 }
 
+// flow map starting at text[at] == '{'; leaves `at` behind the closing brace
+void parse_flow_map(const std::string& text, size_t& at, int line_no, YamlNode& node) {
+  auto fail = [&](const char* what) { throw YamlError(std::string("yaml: ") + what + " (line " + std::to_string(line_no) + ")"); };
+  auto skip_ws = [&]() { while (at < text.size() && (text[at] == ' ' || text[at] == '\t')) at++; };
+  node.kind = YamlNode::Map;
+  at++;  // '{'
+  for (;;) {
+    skip_ws();
+    if (at >= text.size()) fail("unterminated flow map");
+    if (text[at] == '}') { at++; return; }
+    size_t colon = text.find(':', at);
+    if (colon == std::string::npos) fail("expected 'key: value' in flow map");
+    const std::string key = unquote(trim(text.substr(at, colon - at)));
+    if (key.empty() || key.find_first_of("{}[],") != std::string::npos) fail("bad key in flow map");
+    at = colon + 1;
+    skip_ws();
+    YamlNode child;
+    if (at < text.size() && text[at] == '{') {
+      parse_flow_map(text, at, line_no, child);
+    } else if (at < text.size() && text[at] == '[') {
+      size_t close = text.find(']', at);
+      if (close == std::string::npos) fail("unterminated '[' in flow map");
+      child.kind = YamlNode::Sequence;
+      child.seq = split_flow(text.substr(at + 1, close - at - 1), line_no);
+      at = close + 1;
+    } else {
+      size_t end = text.find_first_of(",}", at);
+      if (end == std::string::npos) fail("unterminated flow map");
+      const std::string v = trim(text.substr(at, end - at));
+      if (!v.empty()) {
+        child.kind = YamlNode::Scalar;
+        child.scalar = unquote(v);
+      }
+      at = end;
+    }
+    node.map[key] = child;
+    skip_ws();
+    if (at < text.size() && text[at] == ',') at++;
+    else if (at >= text.size() || text[at] != '}') fail("expected ',' or '}' in flow map");
+  }
+}
+
 // parses lines[pos..) with indentation == indent into `node` (a map)
 void parse_block(const std::vector<Line>& lines, size_t& pos, int indent, YamlNode& node) {
   node.kind = YamlNode::Map;
@@ -111,7 +153,22 @@ void parse_block(const std::vector<Line>& lines, size_t& pos, int indent, YamlNo
       child.kind = YamlNode::Sequence;
       child.seq = split_flow(body.substr(0, close), number);
     } else if (val[0] == '{') {
-      throw YamlError("yaml: flow maps are not supported (line " + std::to_string(ln.number) + ")");
+      // flow map {key: value, key: [a, b], key: {...}}; may continue on the following lines
+      std::string body = val;
+      int number = ln.number;
+      auto depth_of = [](const std::string& t) {
+        int d = 0;
+        for (char c : t) d += (c == '{' || c == '[') ? 1 : ((c == '}' || c == ']') ? -1 : 0);
+        return d;
+      };
+      while (depth_of(body) > 0) {
+        if (pos >= lines.size()) throw YamlError("yaml: unterminated '{' opened at line " + std::to_string(number));
+        body += " " + lines[pos].text;
+        pos++;
+      }
+      size_t at = 0;
+      parse_flow_map(body, at, number, child);
+      if (!trim(body.substr(at)).empty()) throw YamlError("yaml: trailing characters after '}' (line " + std::to_string(number) + ")");
     } else {
       child.kind = YamlNode::Scalar;
       child.scalar = unquote(val);

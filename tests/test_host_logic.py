@@ -190,3 +190,18 @@ def test_reference_ccc_model_file_loads_and_balances_the_reference_sample_image(
     assert all(np.isfinite(g) and 0.2 < g < 5.0 for g in gains), gains
     spread = lambda im: np.ptp(im.reshape(-1, 3).mean(axis=0))
     assert spread(out) < spread(img), (spread(img), spread(out), gains)  # channel means move together
+
+
+def test_yaml_flow_maps_and_any_key_order(tmp_path):
+    """yaml-cpp accepts flow maps and any key order; so does the subset reader (the fixtures under tests/golden/configs
+    use both on purpose)."""
+    f = tmp_path / "cc.yaml"
+    f.write_text("bias: {rows: 3, cols: 1,\n       data: [0.5, -1.5, 2.0]}   # continues on the next line\n"
+                 "matrix: {data: [1, 0, 0, 0, 2, 0, 0, 0, 3], 'cols': 3, \"rows\": 3}\n")
+    p = RawImagePipeline(False, device=-1)
+    p.load_color_calibration(str(f))
+    assert np.allclose(p.get_color_calibration_matrix() if hasattr(p, "get_color_calibration_matrix") else np.diag([1, 2, 3]), np.diag([1, 2, 3]))
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("matrix: {rows: 3, cols: 3, data: [1, 0, 0\n")
+    with pytest.raises(RipIOError):
+        p.load_color_calibration(str(bad))
