@@ -377,7 +377,11 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     // persistent workgroups would leave most of the chip idle while a fifth of them does a second chunk; four
     // times as many, shorter units let the dispatcher even that out (config2: 0.80 -> 0.75 ms) and 16 frames
     // still amortise the per-item setup (FP64 vignetting mask, addresses).
-    const int frames_per_visit = std::max(1, tune_env("RIP_CHAIN_FRAMES", 16));
+    // The cheap stage sets (no Lab / HSV round trip) are HBM-bound and stream best one frame at a time -- a frame
+    // is contiguous, the next frame of the batch is megabytes away (config5, debayer only: 2.00 ms at 16 frames
+    // per visit, 1.74 ms at 1 = 4.9 TB/s); the VALU-bound sets want their per-item setup amortised (16).
+    const bool valu_bound = (p.stage_bits & (ST_VIG | ST_HSV)) != 0;
+    const int frames_per_visit = std::max(1, tune_env("RIP_CHAIN_FRAMES", valu_bound ? 16 : 1));
     int groups = std::max(cap / blocks, (p.n_frames + frames_per_visit - 1) / frames_per_visit);
     groups = std::max(1, std::min(p.n_frames, groups));
     dim3 grid(blocks, groups);
