@@ -79,3 +79,42 @@ def test_random_configuration_on_colour_and_mono_input(gpu_pipe, oracle, seed):
     got = gpu_pipe.process(img, encoding)
     ref, _ = oracle_run(oracle, c, img, encoding)
     assert_images_equal(got, ref.reshape(got.shape), what)
+
+
+@pytest.mark.parametrize("seed", range(max(1, N_BAYER // 3)))
+def test_random_ccc_sequences(gpu_pipe, oracle, seed):
+    """Convolutional colour constancy on random sizes (720x540 takes the 2x2 area path of the resize), flips,
+    thresholds and Kalman models; a short sequence per case so the filter state carries from frame to frame,
+    every other case as one resident batch."""
+    import torch
+    rng = np.random.default_rng(12000 + seed)
+    if rng.random() < 0.3:
+        w, h = 720, 540
+    else:
+        w, h = int(rng.integers(24, 120)) * 4, int(rng.integers(20, 100)) * 2
+    pattern = str(rng.choice(PATTERNS))
+    filt, bias = synth.ccc_model()
+    gpu_pipe.set_ccc_model(filt, bias)
+    occ = oracle.CCC(filt, bias)
+    kal = (0.0, 1.0) if rng.random() < 0.3 else (1.0, float(rng.uniform(1, 20)))
+    occ.set_kalman_model(*kal)
+    gpu_pipe.set_ccc_kalman_model(*kal)
+    angle = int(rng.choice([0, 90, 180, 270]))
+    c = cfg(wb=True, wb_method="ccc", wb_bright=float(rng.uniform(0.6, 1.0)), wb_dark=float(rng.uniform(0.0, 0.3)),
+            wb_temporal=bool(rng.random() < 0.7), flip=bool(rng.random() < 0.5), flip_angle=angle,
+            gamma=bool(rng.random() < 0.5), gamma_k=0.9, ce=bool(rng.random() < 0.5), ce_sat=1.2)
+    configure(gpu_pipe, c)
+    gpu_pipe.reset_white_balance_temporal_consistency()
+    occ.reset()
+    n = int(rng.integers(2, 6))
+    frames = [synth.gen_frame(w, h, pattern, seed=31 * seed + i, kind="scene", tint=(0.6 + 0.08 * i, 1.0, 0.5 + 0.05 * i)) for i in range(n)]
+    what = "ccc seed %d: %dx%d %s kalman %s %s" % (seed, w, h, pattern, kal, {k: c[k] for k in ("wb_bright", "wb_dark", "wb_temporal", "flip", "flip_angle")})
+    if seed % 2:
+        out = gpu_pipe.apply_device(torch.from_numpy(np.stack(frames)).cuda(), pattern)
+        torch.cuda.synchronize()
+        got = list(out.cpu().numpy())
+    else:
+        got = [gpu_pipe.process(f, pattern) for f in frames]
+    for i in range(n):
+        ref, _ = oracle_run(oracle, c, frames[i], pattern, ccc=occ)
+        assert_images_equal(got[i], ref, what + " frame %d/%d" % (i, n))
