@@ -788,8 +788,19 @@ rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, s
     if (in_step == 0) in_step = (size_t)cols * channels;
     if (in_frame_stride == 0) in_frame_stride = in_step * rows;
     if (in_step < (size_t)cols * channels) throw InvalidArgument("input row pitch smaller than a row");
-    run_batch(p, pl, static_cast<const uint8_t*>(d_in), in_step, in_frame_stride, n_frames, rows, cols, static_cast<uint8_t*>(d_out),
-              out_step, out_frame_stride, static_cast<uint8_t*>(d_tap_debayered), static_cast<uint8_t*>(d_tap_color));
+    // several kernels put the frame index on gridDim.y (<= 65535): longer batches go through in slices.  The
+    // frames of a stream are processed in order either way (the ccc Kalman state lives on the device).
+    constexpr int kMaxFramesPerLaunch = 16384;
+    const size_t o_step = out_step ? out_step : (size_t)pl.out_cols * pl.channels;
+    const size_t o_stride = out_frame_stride ? out_frame_stride : o_step * pl.out_rows;
+    const size_t tap_frame = (size_t)pl.mid_rows * pl.mid_cols * pl.channels;
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxFramesPerLaunch) {
+      const int n = std::min(kMaxFramesPerLaunch, n_frames - f0);
+      uint8_t* tap_deb = d_tap_debayered ? static_cast<uint8_t*>(d_tap_debayered) + (size_t)f0 * tap_frame : nullptr;
+      uint8_t* tap_col = d_tap_color ? static_cast<uint8_t*>(d_tap_color) + (size_t)f0 * tap_frame : nullptr;
+      run_batch(p, pl, static_cast<const uint8_t*>(d_in) + (size_t)f0 * in_frame_stride, in_step, in_frame_stride, n, rows, cols,
+                static_cast<uint8_t*>(d_out) + (size_t)f0 * o_stride, o_step, o_stride, tap_deb, tap_col);
+    }
   });
 }
 

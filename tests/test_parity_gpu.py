@@ -268,6 +268,25 @@ def test_batch_with_many_frames_per_workgroup(gpu_pipe, oracle, monkeypatch, wb)
         assert_images_equal(out[i], ref, "frame %d of %d (%s)" % (i, n, wb))
 
 
+def test_very_long_batch_is_sliced(gpu_pipe, oracle):
+    """More frames than a grid dimension holds: the batch goes through in slices of 16384; 40 000 tiny frames, a few
+    of them checked against the oracle, all of them against the frame pattern they repeat."""
+    import torch
+    w, h, n = 16, 8, 40000
+    c = cfg(wb=True, wb_method="grey_world", gamma=True, gamma_k=0.9, flip=True, flip_angle=180)
+    configure(gpu_pipe, c)
+    base = np.stack([synth.gen_frame(w, h, "bayer_rggb8", seed=600 + i, kind="uniform") for i in range(7)])
+    frames = torch.from_numpy(base).cuda()[torch.arange(n, device="cuda") % 7]
+    out = gpu_pipe.apply_device(frames.contiguous(), "bayer_rggb8")
+    torch.cuda.synchronize()
+    refs = [oracle_run(oracle, c, base[i], "bayer_rggb8")[0] for i in range(7)]
+    out7 = out.reshape(-1, h, w, 3)
+    for i in (0, 1, 6, 16383, 16384, 16385, 32768, n - 1):
+        assert_images_equal(out7[i].cpu().numpy(), refs[i % 7], "frame %d of %d" % (i, n))
+    expect = torch.from_numpy(np.stack(refs)).cuda()[torch.arange(n, device="cuda") % 7]
+    assert torch.equal(out7, expect)
+
+
 def test_full_size_batch_equals_single_frames(gpu_pipe):
     """Size-independent property at BASELINE's size: a resident batch gives, frame by frame, what the
     single-frame call gives (which test_full_chain_full_size_2448x2048 checks against the oracle)."""
