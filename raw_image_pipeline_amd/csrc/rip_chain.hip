@@ -355,6 +355,20 @@ bool chain_uses_rot_path(const ChainParams& p) {
          (!p.tap || ((reinterpret_cast<uintptr_t>(p.tap) & 1u) == 0 && p.tap_frame_stride % 2 == 0));
 }
 
+// gridDim.y: how many groups of frames the batch is split into (every kernel here walks the frames of its group
+// innermost).  At most 16 frames per item visit (RIP_CHAIN_FRAMES): 2448 chunks on 2048 persistent workgroups would
+// leave most of the chip idle while a fifth of them does a second chunk; four times as many, shorter units let the
+// dispatcher even that out (config2: 0.80 -> 0.75 ms per 64 frames) and 16 frames still amortise the per-item setup
+// (FP64 vignetting mask, addresses).  The cheap stage sets (no Lab / HSV round trip) are HBM-bound and stream best one
+// frame at a time -- a frame is contiguous, the next frame of the batch is megabytes away (config5, debayer only:
+// 2.00 ms at 16 frames per visit, 1.65 ms at 1 = 5.1 TB/s).
+static int frame_groups(const ChainParams& p, int cap, int blocks) {
+  const bool valu_bound = (p.stage_bits & (ST_VIG | ST_HSV)) != 0;
+  const int frames_per_visit = std::max(1, tune_env("RIP_CHAIN_FRAMES", valu_bound ? 16 : 1));
+  const int groups = std::max(cap / std::max(blocks, 1), (p.n_frames + frames_per_visit - 1) / frames_per_visit);
+  return std::max(1, std::min(p.n_frames, groups));
+}
+
 void launch_chain(const ChainParams& p, hipStream_t stream) {
   if (p.n_frames <= 0) return;
   if (chain_uses_rot_path(p)) {
@@ -362,7 +376,7 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     const int tiles = tiles_x * tiles_y;
     const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
     const int blocks = std::min(cap, tiles);
-    const int groups = std::max(1, std::min(p.n_frames, cap / blocks));
+    const int groups = frame_groups(p, cap, blocks);
     hipLaunchKernelGGL(chain_rot_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, tiles_x, tiles);
     return;
   }
@@ -373,18 +387,7 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     // persistent grid: at most 256 CUs x 8 workgroups, a multiple of 8 (one share per XCD)
     const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
-    // blockIdx.y splits the batch: at most 16 frames per item visit (RIP_CHAIN_FRAMES).  2448 chunks on 2048
-    // persistent workgroups would leave most of the chip idle while a fifth of them does a second chunk; four
-    // times as many, shorter units let the dispatcher even that out (config2: 0.80 -> 0.75 ms) and 16 frames
-    // still amortise the per-item setup (FP64 vignetting mask, addresses).
-    // The cheap stage sets (no Lab / HSV round trip) are HBM-bound and stream best one frame at a time -- a frame
-    // is contiguous, the next frame of the batch is megabytes away (config5, debayer only: 2.00 ms at 16 frames
-    // per visit, 1.74 ms at 1 = 4.9 TB/s); the VALU-bound sets want their per-item setup amortised (16).
-    const bool valu_bound = (p.stage_bits & (ST_VIG | ST_HSV)) != 0;
-    const int frames_per_visit = std::max(1, tune_env("RIP_CHAIN_FRAMES", valu_bound ? 16 : 1));
-    int groups = std::max(cap / blocks, (p.n_frames + frames_per_visit - 1) / frames_per_visit);
-    groups = std::max(1, std::min(p.n_frames, groups));
-    dim3 grid(blocks, groups);
+    dim3 grid(blocks, frame_groups(p, cap, blocks));
     switch (p.stage_bits & 15) {
 #define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream); break;
       RIP_CASE(0) RIP_CASE(1) RIP_CASE(2) RIP_CASE(3) RIP_CASE(4) RIP_CASE(5) RIP_CASE(6) RIP_CASE(7)
@@ -398,7 +401,7 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     const int items = p.rows * (p.cols / 4);
     const int chunks = (items + kBlock - 1) / kBlock;
     const int blocks = std::min(2048, chunks);
-    const int groups = std::max(1, std::min(p.n_frames, 2048 / blocks));
+    const int groups = frame_groups(p, 2048, blocks);
     hipLaunchKernelGGL(chain_color_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, im, items);
     return;
   }
