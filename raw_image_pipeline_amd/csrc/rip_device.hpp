@@ -361,31 +361,26 @@ __device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, 
   int S = sat_round_u8((float)s * p.hsv_gain[1]);
   int V = sat_round_u8((float)v * p.hsv_gain[2]);
   float fh = (float)H, fs = (float)S * (1.f / 255.f), fv = (float)V * (1.f / 255.f);
-  float ob, og, orr;
-  if (fs == 0.f) {
-    ob = og = orr = fv;
-  } else {
-    fh = fh * (6.f / 180.f);
-    if (fh >= 6.f) fh = fh - 6.f;  // fmod(h, 6): h <= 255/30 < 12
-    int sector = (int)fh;          // floor, h >= 0
-    fh = fh - (float)sector;
-    if ((unsigned)sector >= 6u) {
-      sector = 0;
-      fh = 0.f;
-    }
-    float t0 = fv;
-    float t1 = fv * (1.f - fs);
-    float t2 = fv * (1.f - fs * fh);
-    float t3 = fv * (1.f - fs * (1.f - fh));
-    switch (sector) {
-      case 0: ob = t1; og = t3; orr = t0; break;
-      case 1: ob = t1; og = t0; orr = t2; break;
-      case 2: ob = t3; og = t0; orr = t1; break;
-      case 3: ob = t0; og = t2; orr = t1; break;
-      case 4: ob = t0; og = t1; orr = t3; break;
-      default: ob = t2; og = t1; orr = t0; break;
-    }
-  }
+  // HSV2RGB_f (color_hsv.cpp): tab = {v, v(1-s), v(1-s*f), v(1-s*(1-f))}, (b, g, r) = tab[sector_data[sector][..]].
+  // Branch-free: the per-lane sector would otherwise run up to six divergent case bodies per pixel.  With s == 0
+  // every entry of tab equals v exactly, so OpenCV's early-out needs no branch either.
+  fh = fh * (6.f / 180.f);
+  fh = fh >= 6.f ? fh - 6.f : fh;  // fmod(h, 6): h <= 255/30 < 12
+  int sector = (int)fh;            // floor, h >= 0
+  fh = fh - (float)sector;
+  const bool bad = (unsigned)sector >= 6u;
+  sector = bad ? 0 : sector;
+  fh = bad ? 0.f : fh;
+  const float t0 = fv;
+  const float t1 = fv * (1.f - fs);
+  const float t2 = fv * (1.f - fs * fh);
+  const float t3 = fv * (1.f - fs * (1.f - fh));
+  // sector: 0 (t1,t3,t0)  1 (t1,t0,t2)  2 (t3,t0,t1)  3 (t0,t2,t1)  4 (t0,t1,t3)  5 (t2,t1,t0)
+  const float m = (sector & 1) ? t2 : t3;  // the f-dependent entry of this sector
+  const unsigned oh = 1u << sector;
+  const float ob = (oh & 0x24u) ? m : ((oh & 0x03u) ? t1 : t0);
+  const float og = (oh & 0x09u) ? m : ((oh & 0x06u) ? t0 : t1);
+  const float orr = (oh & 0x12u) ? m : ((oh & 0x21u) ? t0 : t1);
   b = sat_round_u8(ob * 255.f);
   g = sat_round_u8(og * 255.f);
   r = sat_round_u8(orr * 255.f);
