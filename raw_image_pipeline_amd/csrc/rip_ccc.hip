@@ -70,46 +70,60 @@ __device__ __forceinline__ void fetch_block2x2(const SrcView& s, int angle, int 
   fetch_flipped(s, angle, y1, x1, out[3][0], out[3][1], out[3][2]);
 }
 
+// Samples per frame: 360 x 270 (small_size_, convolutional_color_constancy.cpp:22).  kHistBlocks workgroups per frame
+// walk them with the resize geometry and the log table in LDS (ten table reads per sample otherwise go to L2).
+constexpr int kHistBlocks = 24;
 __global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
-  const int frame = blockIdx.y;
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= 360 * 270) return;
-  const int dy = i / 360, dx = i - dy * 360;
-  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
-  int sm[3];
-  int t[4][3];  // taps (y0,x0) (y0,x1) (y1,x0) (y1,x1)
-  if (p.geom.area_fast) {
-    fetch_block2x2(s, p.flip_angle, 2 * dy, 2 * dx, 2 * dy + 1, 2 * dx + 1, t);
-#pragma unroll
-    for (int c = 0; c < 3; c++) sm[c] = (t[0][c] + t[1][c] + t[2][c] + t[3][c] + 2) >> 2;
-  } else {
-    // cv::resize INTER_LINEAR, 8U: Q11 coefficients, two-pass integer arithmetic
-    const int sx = p.geom.xofs[dx];
-    const int sx1 = sx + 1 < p.dcols ? sx + 1 : sx;
-    const int a0 = p.geom.ialpha[dx * 2], a1 = p.geom.ialpha[dx * 2 + 1];
-    const int y0 = p.geom.yofs[dy * 2], y1 = p.geom.yofs[dy * 2 + 1];
-    const int b0 = p.geom.ibeta[dy * 2], b1 = p.geom.ibeta[dy * 2 + 1];
-    fetch_block2x2(s, p.flip_angle, y0, sx, y1, sx1, t);
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      int r0 = t[0][c] * a0 + t[1][c] * a1;
-      int r1 = t[2][c] * a0 + t[3][c] * a1;
-      sm[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-    }
+  __shared__ int s_xofs[360], s_yofs[540];
+  __shared__ short s_ialpha[720], s_ibeta[540];
+  __shared__ float s_log[256];
+  for (int i = threadIdx.x; i < 360; i += kBlock) s_xofs[i] = p.geom.xofs[i];
+  for (int i = threadIdx.x; i < 540; i += kBlock) {
+    s_yofs[i] = p.geom.yofs[i];
+    s_ibeta[i] = p.geom.ibeta[i];
   }
-  // calculateHistogramFeature (:210-271)
-  float fb = (float)sm[0], fg = (float)sm[1], fr = (float)sm[2];
-  float gray = fb * 0.114f + fg * 0.587f + fr * 0.299f;
-  bool ok = !(gray > p.upper) && (gray > p.lower);
-  if (sm[0] == 0 || sm[1] == 0 || sm[2] == 0) ok = false;  // log(0) = -inf is skipped
-  if (!ok) return;
-  const float bin_size = 1.0f / 64.0f, uv0 = -1.421875f;
-  float lb = p.tabs->log_tab[sm[0]], lg = p.tabs->log_tab[sm[1]], lr = p.tabs->log_tab[sm[2]];
-  int u = (int)roundf((lg - lr - uv0) / bin_size);
-  int v = (int)roundf((lg - lb - uv0) / bin_size);
-  u = clampi(u, 0, 255);
-  v = clampi(v, 0, 255);
-  atomicAdd(&p.hist_counts[(size_t)frame * 65536 + u * 256 + v], 1u);
+  for (int i = threadIdx.x; i < 720; i += kBlock) s_ialpha[i] = p.geom.ialpha[i];
+  s_log[threadIdx.x] = p.tabs->log_tab[threadIdx.x];
+  __syncthreads();
+  const int frame = blockIdx.y;
+  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < 360 * 270; i += kHistBlocks * kBlock) {
+    const int dy = i / 360, dx = i - dy * 360;
+    int sm[3];
+    int t[4][3];  // taps (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+    if (p.geom.area_fast) {
+      fetch_block2x2(s, p.flip_angle, 2 * dy, 2 * dx, 2 * dy + 1, 2 * dx + 1, t);
+#pragma unroll
+      for (int c = 0; c < 3; c++) sm[c] = (t[0][c] + t[1][c] + t[2][c] + t[3][c] + 2) >> 2;
+    } else {
+      // cv::resize INTER_LINEAR, 8U: Q11 coefficients, two-pass integer arithmetic
+      const int sx = s_xofs[dx];
+      const int sx1 = sx + 1 < p.dcols ? sx + 1 : sx;
+      const int a0 = s_ialpha[dx * 2], a1 = s_ialpha[dx * 2 + 1];
+      const int y0 = s_yofs[dy * 2], y1 = s_yofs[dy * 2 + 1];
+      const int b0 = s_ibeta[dy * 2], b1 = s_ibeta[dy * 2 + 1];
+      fetch_block2x2(s, p.flip_angle, y0, sx, y1, sx1, t);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        int r0 = t[0][c] * a0 + t[1][c] * a1;
+        int r1 = t[2][c] * a0 + t[3][c] * a1;
+        sm[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      }
+    }
+    // calculateHistogramFeature (:210-271)
+    float fb = (float)sm[0], fg = (float)sm[1], fr = (float)sm[2];
+    float gray = fb * 0.114f + fg * 0.587f + fr * 0.299f;
+    bool ok = !(gray > p.upper) && (gray > p.lower);
+    if (sm[0] == 0 || sm[1] == 0 || sm[2] == 0) ok = false;  // log(0) = -inf is skipped
+    if (!ok) continue;
+    const float bin_size = 1.0f / 64.0f, uv0 = -1.421875f;
+    float lb = s_log[sm[0]], lg = s_log[sm[1]], lr = s_log[sm[2]];
+    int u = (int)roundf((lg - lr - uv0) / bin_size);
+    int v = (int)roundf((lg - lb - uv0) / bin_size);
+    u = clampi(u, 0, 255);
+    v = clampi(v, 0, 255);
+    atomicAdd(&p.hist_counts[(size_t)frame * 65536 + u * 256 + v], 1u);
+  }
 }
 
 // 256-point radix-2 DIT FFT in LDS, 128 threads, same butterfly order as the host reference
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(256) void ccc_argmax_kernel(CccParams p) {
 
 void launch_ccc_estimate(const CccParams& p, hipStream_t stream) {
   if (p.n_frames <= 0) return;
-  hipLaunchKernelGGL(ccc_hist_kernel, dim3((360 * 270 + kBlock - 1) / kBlock, p.n_frames), dim3(kBlock), 0, stream, p);
+  hipLaunchKernelGGL(ccc_hist_kernel, dim3(kHistBlocks, p.n_frames), dim3(kBlock), 0, stream, p);
   hipLaunchKernelGGL(ccc_fft_rows_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
   hipLaunchKernelGGL(ccc_fft_cols_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(ccc_ifft_rows_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
