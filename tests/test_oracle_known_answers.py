@@ -474,3 +474,25 @@ def test_remap_tracks_scipy_bilinear(oracle):
         gy, gx = np.gradient(img[..., c].astype(np.float64))
         slack = 1.0 + (np.abs(gx).max() + np.abs(gy).max()) / 64.0
         assert np.abs(got[..., c] - ref).max() <= slack, (c, np.abs(got[..., c] - ref).max(), slack)
+
+
+def test_lab_gamma_tables_do_not_depend_on_the_pow_implementation(oracle):
+    """OpenCV builds sRGBGammaTab_b / sRGBInvGammaTab_b with its softfloat pow, the oracle with libm's.  Evaluated with
+    50 digits, every entry is >= 13 (forward) / >= 5.5 (inverse, entry 3654 = 242.49992) float32 ulps of its value away
+    from a rounding boundary, and the oracle's tables equal the exactly rounded ones: a pow that is good to a few ulps
+    cannot produce different integers."""
+    from decimal import Decimal as D, getcontext
+    getcontext().prec = 50
+    gamma = lambda x: x / D("12.92") if x <= D("0.04045") else ((x + D("0.055")) / D("1.055")) ** D("2.4")
+    inv = lambda x: x * D("12.92") if x <= D("0.0031308") else D("1.055") * x ** (D(1) / D("2.4")) - D("0.055")
+    cases = [("srgb_gamma", [D(2040) * gamma(D(i) / D(255)) for i in range(256)], 13.0),
+             ("inv_gamma", [D(255) * inv(D(i) / D(4096)) for i in range(4096)], 5.0)]
+    for name, exact, min_ulps in cases:
+        tab = oracle.table(name)
+        assert len(tab) == len(exact)
+        worst = 1e9
+        for i, v in enumerate(exact):
+            assert int(v.to_integral_value(rounding="ROUND_HALF_EVEN")) == int(tab[i]), (name, i)
+            if v > 0:
+                worst = min(worst, float(abs((v % 1) - D("0.5"))) / float(np.spacing(np.float32(float(v)))))
+        assert worst >= min_ulps, (name, worst)
