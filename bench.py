@@ -167,6 +167,15 @@ def cpu_baseline(width, height, pattern, seconds):
                       % (done, width, height, pattern, cores, el)}
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "frames/sec at 2448\u00d72048 bayer_rggb8 full chain; achieved HBM GB/s vs roofline"
+
+
 def hbm_probe(torch, nbytes=1 << 30, reps=10):
     """Streaming copy and read-only rates of this GPU (torch elementwise kernels), GB/s of bytes moved."""
     src = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda").fill_(1)
@@ -281,7 +290,7 @@ def main():
         roofline["empirical"] = dict(probe, frac_of_copy=round(achieved / probe["copy_GBps"], 4) if probe["copy_GBps"] else None,
                                      frac_of_read=round(achieved / probe["read_GBps"], 4) if probe["read_GBps"] else None)
     result = {
-        "metric": "frames/sec at 2448x2048 bayer_rggb8 full chain; achieved HBM GB/s vs roofline",
+        "metric": baseline_metric(),
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
