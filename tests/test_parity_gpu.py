@@ -360,6 +360,15 @@ def test_ccc_white_balance_sequence_config3(gpu_pipe, oracle):
     assert len(set(seen[n:])) > 1, "H = I: the estimate must follow the drifting tint"
 
 
+def test_config1_640x480_debayer_and_default_gamma(gpu_pipe, oracle):
+    """BASELINE configs[0]: one 640x480 bayer_rggb8 frame, debayer + gamma (method `default`, the same LUT on the
+    CPU path) only -- the plumbing case, through the same C-ABI call a reference caller makes."""
+    frame = synth.gen_frame(640, 480, "bayer_rggb8", seed=0, kind="scene")
+    c = cfg(gamma=True, gamma_method="default", gamma_k=0.8)
+    got = run_both(gpu_pipe, oracle, c, frame, "bayer_rggb8", TOL_EXACT, what="config 1")
+    assert got.shape == (480, 640, 3) and gpu_pipe.last_encoding == "bgr8"
+
+
 def test_config3_full_size_1920x1200_ccc_batch(gpu_pipe, oracle):
     """BASELINE configs[2] at its own size: 1920x1200 gbrg8, ccc with the Kalman filter following a drifting tint,
     HSV enhancer; four frames as ONE resident batch (the estimator's sequential Kalman step runs on the device)."""
