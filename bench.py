@@ -277,7 +277,11 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_s * 1e3, 4),
                 "launches": dom_n,
-                "kernel_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()}}
+                "kernel_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()},
+                # algorithmic GB/s of every streaming class (same definition as `achieved`), for the non-dominant kernels
+                "kernel_GBps": {k: round(bytes_per_px(k, args.batch) * (orows * ocols if k == "remap" else px) * args.batch /
+                                         (v[0] / max(v[1], 1) * 1e-3) / 1e9, 1)
+                                for k, v in prof.items() if v[0] > 0 and bytes_per_px(k, args.batch) > 0}}
 
     if rank != 0:
         if world > 1:
