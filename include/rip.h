@@ -207,6 +207,10 @@ rip_status rip_profile_begin(rip_pipeline* p, int max_records);
 rip_status rip_profile_end(rip_pipeline* p, double ms_sum[4], int count[4]);
 /* Host-built tables the kernels use (same ids as oracle ripo_table, plus 8: gamma LUT). */
 int rip_get_table(rip_pipeline* p, int which, int32_t* out, int capacity);
+/* The vignetting mask plane the kernels multiply L by (VignettingCorrectionModule::precomputeVignettingMask,
+ * vignetting_correction.cpp:32-63) for a rows x cols frame with the handle's current scale / a2 / a4:
+ * rows * cols floats, row-major.  Host computation only; works on RIP_DEVICE_NONE handles. */
+rip_status rip_get_vignetting_mask(rip_pipeline* p, int rows, int cols, float* out, size_t capacity_floats);
 const char* rip_version(void);
 
 #ifdef __cplusplus

@@ -30,30 +30,34 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
+def build(force=False, verbose=False, out=None, extra_flags=None, tag=""):
+    """out / extra_flags / tag: A/B variants for experiments (tools/ab_chain.py), e.g. extra_flags=["-DRIP_X=1"],
+    out=".../variants/x.so"; the default build takes no extra flags beyond $RIP_EXTRA_FLAGS."""
+    if out is None and not force and up_to_date():
         return OUT
+    out = out or OUT
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build" + tag)
+    os.makedirs(bdir, exist_ok=True)
     for s in SOURCES:
-        obj = os.path.join(HERE, "build", os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + os.environ.get("RIP_EXTRA_FLAGS", "").split() + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        obj = os.path.join(bdir, os.path.splitext(s)[0] + ".o")
+        cmd = [hipcc()] + FLAGS + os.environ.get("RIP_EXTRA_FLAGS", "").split() + list(extra_flags or []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     for s, pr in procs:
-        out, _ = pr.communicate()
+        log, _ = pr.communicate()
         if pr.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (s, out))
-        if verbose and out.strip():
-            print(out)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, log))
+        if verbose and log.strip():
+            print(log)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -113,8 +113,9 @@ struct rip_pipeline {
   std::vector<float> h_map;
   DevBuf d_map;
   bool map_dirty = true, map_uploaded = false;
-  // vignetting constants per geometry
-  rip::VignetteConst vig;
+  // vignetting mask plane per geometry (float, rows x cols)
+  std::vector<float> h_vig;
+  DevBuf d_vig;
   int vig_rows = -1, vig_cols = -1;
   bool vig_dirty = true;
   // ccc
@@ -147,7 +148,7 @@ struct rip_pipeline {
     (void)hipSetDevice(device);
     for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
     for (DevBuf* b : {&d_tabs, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
-                      &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col, &d_plan_words,
+                      &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col, &d_vig, &d_plan_words,
                       &d_plan_tiles, &d_plan_border})
       b->release();
   }
@@ -273,7 +274,10 @@ void ensure_tables(rip_pipeline* p) {
 
 void ensure_vignette(rip_pipeline* p, int rows, int cols) {
   if (!p->vig_dirty && p->vig_rows == rows && p->vig_cols == cols) return;
-  p->vig = rip::build_vignette_const(rows, cols, p->m.vig_scale, p->m.vig_a2, p->m.vig_a4);
+  rip::build_vignette_mask(rows, cols, p->m.vig_scale, p->m.vig_a2, p->m.vig_a4, p->h_vig);
+  p->d_vig.reserve(p->h_vig.size() * sizeof(float));
+  HIP_CHECK(hipMemcpyAsync(p->d_vig.ptr, p->h_vig.data(), p->h_vig.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
+  HIP_CHECK(hipStreamSynchronize(p->stream));
   p->vig_rows = rows;
   p->vig_cols = cols;
   p->vig_dirty = false;
@@ -572,11 +576,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   for (int i = 0; i < 3; i++) c.cc_bias[i] = (float)p->m.cc_bias[i];
   if (pl.stage_bits & rip::ST_VIG) {
     ensure_vignette(p, pl.mid_rows, pl.mid_cols);
-    c.vig_a2 = p->vig.a2;
-    c.vig_a4 = p->vig.a4;
-    c.vig_inv_max = p->vig.inv_max;
-    c.vig_scale = p->vig.scale;
-    c.vig_has_max = p->vig.has_max;
+    c.vig_mask = p->d_vig.as<float>();
   }
   // cv::Scalar(hue_gain_, saturation_gain_, value_gain_) on (H,S,V), color_enhancer.cpp:42
   c.hsv_gain[0] = (float)p->m.ce_hue_gain;
@@ -1141,6 +1141,16 @@ rip_status rip_profile_end(rip_pipeline* p, double ms_sum[RIP_KERNEL_COUNT], int
     p->prof_on = false;
     p->prof_used = 0;
     p->prof_ids.clear();
+  });
+}
+
+rip_status rip_get_vignetting_mask(rip_pipeline* p, int rows, int cols, float* out, size_t capacity_floats) {
+  if (!p) return RIP_ERR_INVALID_ARGUMENT;
+  return guarded(p, [&] {
+    if (rows < 1 || cols < 1 || !out || capacity_floats < (size_t)rows * cols) throw InvalidArgument("vignetting mask: bad size / buffer");
+    std::vector<float> m;
+    rip::build_vignette_mask(rows, cols, p->m.vig_scale, p->m.vig_a2, p->m.vig_a4, m);
+    std::memcpy(out, m.data(), m.size() * sizeof(float));
   });
 }
 

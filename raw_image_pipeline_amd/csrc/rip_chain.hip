@@ -3,6 +3,8 @@
 // Shared device code and the stage-by-stage reference citations: rip_device.hpp.
 #include "rip_device.hpp"
 
+#include <cstdio>
+
 namespace rip {
 namespace {
 
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
       t[1] = (uint8_t)g;
       t[2] = (uint8_t)r;
     }
-    pointwise<-1, -1>(p, w, tb, fwdf, p.tabs->lab_inv_pk, (p.stage_bits & ST_VIG) ? vignette_mask(p, yd, xd) : 1.0f, b, g, r);
+    pointwise<-1, -1>(p, w, tb, fwdf, p.tabs->lab_inv_pk, (p.stage_bits & ST_VIG) ? p.vig_mask[(size_t)yd * p.dcols + xd] : 1.0f, b, g, r);
     uint8_t* o = dst + (size_t)yd * p.dst_step + (size_t)xd * 3;
     o[0] = (uint8_t)b;
     o[1] = (uint8_t)g;
@@ -49,24 +51,103 @@ __global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
 }
 
 
-template <int BITS, int WB>
-__global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
-  __shared__ LdsTabs<BITS> tb;
-  __shared__ float s_fwd[9];
-  __shared__ int s_inv[6];
-  tb.load(p.tabs);
-  if (threadIdx.x < 9) {
-    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
-    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
+// Tables of the fast kernel in LDS: only what the compile-time stage set reads.
+template <bool ON, typename T>
+struct OptTab {
+  T v;
+};
+template <typename T>
+struct OptTab<false, T> {};
+struct GammaTab {
+  uint8_t lut[256];
+};
+struct HsvTab {
+  int32_t sdiv[256], hdiv[256];
+};
+template <int BITS>
+struct FastTabs {
+  static constexpr bool kVig = (BITS & ST_VIG) != 0;
+  static constexpr bool kHsv = (BITS & ST_HSV) != 0;
+  static constexpr bool kGamma = (BITS & ST_GAMMA) != 0 && !kVig;  // with vignetting the LUT is folded into VigTabs::lin
+  OptTab<kVig, VigTabs> vig;
+  OptTab<kGamma, GammaTab> gam;
+  OptTab<kHsv, HsvTab> hsv;
+  __device__ __forceinline__ int sdiv(int i) const {
+    if constexpr (kHsv) return hsv.v.sdiv[i];
+    return 0;
   }
+  __device__ __forceinline__ int hdiv(int i) const {
+    if constexpr (kHsv) return hsv.v.hdiv[i];
+    return 0;
+  }
+  template <int NT>
+  __device__ __forceinline__ void load(const DevTables* t) {
+    if constexpr (kVig) vig.v.template load<NT>(t);
+    if constexpr (kGamma)
+      for (int i = threadIdx.x; i < 64; i += NT) reinterpret_cast<uint32_t*>(gam.v.lut)[i] = reinterpret_cast<const uint32_t*>(t->gamma_lut)[i];
+    if constexpr (kHsv)
+      for (int i = threadIdx.x; i < 256; i += NT) {
+        hsv.v.sdiv[i] = t->sdiv[i];
+        hsv.v.hdiv[i] = t->hdiv[i];
+      }
+  }
+};
+// workgroup size of the fast kernel: the Lab tables are 41 KB, so the vignetting variants share them among
+// 8 waves (3 workgroups = 24 waves per CU); the others keep 256 threads
+#ifndef RIP_VIG_THREADS
+#define RIP_VIG_THREADS 512
+#endif
+#ifndef RIP_VIG_WPE
+#define RIP_VIG_WPE 6  // waves per SIMD the register allocation must allow: 3 workgroups of 512 threads per CU
+#endif
+template <int BITS>
+constexpr int fast_threads() {
+  return (BITS & ST_VIG) ? RIP_VIG_THREADS : 256;
+}
+template <int BITS>
+constexpr int fast_waves_per_simd() {
+  return (BITS & ST_VIG) ? RIP_VIG_WPE : 1;
+}
+
+// The per-pixel stages after the demosaic for the four pixels of one row.
+template <int BITS, int WB>
+__device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const VigRegs& vr,
+                                           const CcRegs& cc, const float (&mask)[4], int (&q)[4][3]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    apply_wb(WB, w, q[k][0], q[k][1], q[k][2]);
+    if constexpr ((BITS & ST_CC) != 0) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
+  }
+  if constexpr ((BITS & ST_VIG) != 0) {
+    vignette4(tb.vig.v, vr, mask, q);  // gamma folded into VigTabs::lin by the host
+  } else if constexpr ((BITS & ST_GAMMA) != 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) q[k][c] = tb.gam.v.lut[q[k][c]];
+  }
+  if constexpr ((BITS & ST_HSV) != 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) apply_hsv(p, tb, q[k][0], q[k][1], q[k][2]);
+  }
+}
+
+template <int BITS, int WB, int NT>
+__global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
+  __shared__ FastTabs<BITS> tb;
+  tb.template load<NT>(p.tabs);
+  VigRegs vr = {};
+  if constexpr ((BITS & ST_VIG) != 0) vr.load();
+  CcRegs cc = {};
+  if constexpr ((BITS & ST_CC) != 0) cc.load(p);
   __syncthreads();
   // Persistent workgroups: the LDS tables are loaded once and amortised over many chunks of
-  // kBlock items.  Block b runs on XCD b % 8 (observed dispatch order; speed only), so each
+  // NT items.  Block b runs on XCD b % 8 (observed dispatch order; speed only), so each
   // XCD walks its own contiguous range of chunks and vertically adjacent row pairs -- which
   // share two halo rows -- hit the same L2.  Frames are the innermost loop: everything that
-  // depends only on the position (item split, vignetting mask in FP64, addresses) is computed
+  // depends only on the position (item split, vignetting mask, addresses) is fetched / computed
   // once per item and reused for every frame of the batch.
-  const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
+  const int chunks_per_frame = (items_per_frame + NT - 1) / NT;
   // small frames do not fill the chip with one frame's chunks: blockIdx.y splits the batch
   const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
   const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
@@ -76,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
   for (int ci = blockIdx.x >> 3; ci < per_xcd; ci += gridDim.x >> 3) {
     const int chunk = xcd * per_xcd + ci;
     if (chunk >= chunks_per_frame) break;
-    const int item = chunk * kBlock + threadIdx.x;
+    const int item = chunk * NT + threadIdx.x;
     if (item >= items_per_frame) continue;
     int pair, grp;
     im.split(item, pair, grp);
@@ -89,8 +170,17 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
       const int yd = flip180 ? p.rows - 1 - (y0 + ly) : y0 + ly;
       dst_off[ly] = __umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u;
       tap_off[ly] = (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u;
+      if constexpr ((BITS & ST_VIG) != 0) {
+        // four consecutive floats of the mask plane: 16-byte aligned (dcols % 4 == 0, xbase % 4 == 0)
+        const float4 m = *reinterpret_cast<const float4*>(p.vig_mask + (size_t)yd * p.dcols + xbase);
+        mask[ly][0] = m.x;
+        mask[ly][1] = m.y;
+        mask[ly][2] = m.z;
+        mask[ly][3] = m.w;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++) mask[ly][k] = (BITS & ST_VIG) ? vignette_mask(p, yd, xbase + k) : 1.0f;
+        for (int k = 0; k < 4; k++) mask[ly][k] = 1.0f;
+      }
     }
     const WindowOffsets wo = window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0);
     const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
@@ -135,8 +225,16 @@ __global__ __launch_bounds__(kBlock) void chain_fast_kernel(ChainParams p, ItemM
           q[k][0] = (int)((v.b >> (8 * k)) & 0xFFu);
           q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
           q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
-          pointwise<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, s_fwd, s_inv, mask[ly][k], q[k][0], q[k][1], q[k][2]);
         }
+        pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, vr, cc, mask[ly], q);
+#ifdef RIP_EXP_EXTRA  // experiment: extra independent full-rate VALU work per row (is the kernel VALU-issue bound?)
+        {
+          unsigned dummy = (unsigned)q[0][0];
+#pragma unroll
+          for (int e = 0; e < RIP_EXP_EXTRA; e++) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(dummy));
+          asm volatile("" ::"v"(dummy));
+        }
+#endif
         store12(dst, dst_off[ly], pack4(q));
       }
     }
@@ -176,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, Item
     const int xbase = flip180 ? p.cols - 4 - x0 : x0;
     float mask[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) mask[k] = vig ? vignette_mask(p, yd, xbase + k) : 1.0f;
+    for (int k = 0; k < 4; k++) mask[k] = vig ? p.vig_mask[(size_t)yd * p.dcols + xbase + k] : 1.0f;
     const unsigned src_off = __umul24((unsigned)ys, (unsigned)p.src_step) + (unsigned)x0 * 3u;
     const unsigned dst_off = __umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u;
     const unsigned tap_off = (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u;
@@ -265,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int ti
       dst_off[k] = __umul24((unsigned)row_d, (unsigned)p.dst_step) + (unsigned)col_d * 3u;
       tap_off[k] = (__umul24((unsigned)row_d, (unsigned)p.dcols) + (unsigned)col_d) * 3u;
 #pragma unroll
-      for (int ly = 0; ly < 2; ly++) mask[ly][k] = vig ? vignette_mask(p, row_d, rot90 ? col_d + 1 - ly : col_d + ly) : 1.0f;
+      for (int ly = 0; ly < 2; ly++) mask[ly][k] = vig ? p.vig_mask[(size_t)row_d * p.dcols + (rot90 ? col_d + 1 - ly : col_d + ly)] : 1.0f;
     }
     const WindowOffsets wo = window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0);
     for (int frame = f_begin; frame < f_end; frame++) {
@@ -311,7 +409,16 @@ __global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int ti
 
 template <int BITS, int WB>
 void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL((chain_fast_kernel<BITS, WB>), grid, dim3(kBlock), 0, stream, p, im, items);
+  constexpr int NT = fast_threads<BITS>();
+  if (std::getenv("RIP_DEBUG_OCC")) {  // development aid: resident workgroups per CU the runtime computes for this variant
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_fast_kernel<BITS, WB, NT>, NT, 0);
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(chain_fast_kernel<BITS, WB, NT>));
+    std::fprintf(stderr, "[rip] chain_fast_kernel<%d,%d,%d>: %d workgroups/CU, %d VGPR, %zu B LDS, grid %u x %u\n", BITS, WB, NT, nb,
+                 fa.numRegs, fa.sharedSizeBytes, grid.x, grid.y);
+  }
+  hipLaunchKernelGGL((chain_fast_kernel<BITS, WB, NT>), grid, dim3(NT), 0, stream, p, im, items);
 }
 
 template <int BITS>
@@ -364,7 +471,7 @@ bool chain_uses_rot_path(const ChainParams& p) {
 // 2.00 ms at 16 frames per visit, 1.65 ms at 1 = 5.1 TB/s).
 static int frame_groups(const ChainParams& p, int cap, int blocks) {
   const bool valu_bound = (p.stage_bits & (ST_VIG | ST_HSV)) != 0;
-  const int frames_per_visit = std::max(1, tune_env("RIP_CHAIN_FRAMES", valu_bound ? 16 : 1));
+  const int frames_per_visit = std::max(1, tune_int("RIP_CHAIN_FRAMES", valu_bound ? 16 : 1));
   const int groups = std::max(cap / std::max(blocks, 1), (p.n_frames + frames_per_visit - 1) / frames_per_visit);
   return std::max(1, std::min(p.n_frames, groups));
 }
@@ -374,7 +481,7 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
   if (chain_uses_rot_path(p)) {
     const int tiles_x = (p.cols / 4 + 3) / 4, tiles_y = (p.rows / 2 + 63) / 64;
     const int tiles = tiles_x * tiles_y;
-    const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
+    const int cap = tune_grid("RIP_CHAIN_BLOCKS", 2048);
     const int blocks = std::min(cap, tiles);
     const int groups = frame_groups(p, cap, blocks);
     hipLaunchKernelGGL(chain_rot_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, tiles_x, tiles);
@@ -383,9 +490,11 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
   if (chain_uses_fast_path(p)) {
     ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
     const int items = (p.rows / 2) * (p.cols / 4);
-    const long long chunks = (long long)((items + kBlock - 1) / kBlock);
-    // persistent grid: at most 256 CUs x 8 workgroups, a multiple of 8 (one share per XCD)
-    const int cap = tune_env("RIP_CHAIN_BLOCKS", 2048);
+    const int nt = (p.stage_bits & ST_VIG) ? fast_threads<ST_VIG>() : fast_threads<0>();
+    const long long chunks = (long long)((items + nt - 1) / nt);
+    // persistent grid: at most 256 CUs x 8 x 256 threads, a multiple of 8 workgroups (one share per XCD; the kernel
+    // strides its chunk loop by gridDim.x / 8)
+    const int cap = std::max(8, tune_grid("RIP_CHAIN_BLOCKS", 2048) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
     dim3 grid(blocks, frame_groups(p, cap, blocks));
     switch (p.stage_bits & 15) {

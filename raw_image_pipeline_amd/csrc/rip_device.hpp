@@ -226,7 +226,33 @@ __device__ __forceinline__ void apply_wb(int mode, const FrameWb& w, int& b, int
   }
 }
 
+// The colour matrix held in VGPRs: as SGPR operands (kernel arguments) every one of the nine multiplies would issue
+// at 4.3 cycles instead of 2.45.  The empty asm keeps hipcc from re-materialising the values from SGPRs.
+struct CcRegs {
+  float m[9];
+  __device__ __forceinline__ void load(const ChainParams& p) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      m[i] = p.cc_m[i];
+      asm volatile("" : "+v"(m[i]));
+    }
+  }
+};
 // color_calibration.cpp:93-103: ((m0*B + m1*G) + m2*R) + bias in float32, no FMA
+__device__ __forceinline__ void apply_cc(const ChainParams& p, const CcRegs& cc, int& b, int& g, int& r) {
+  float fb = (float)b, fg = (float)g, fr = (float)r;
+  float o[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) o[c] = fb * cc.m[c * 3] + fg * cc.m[c * 3 + 1] + fr * cc.m[c * 3 + 2];
+  if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
+    keep_branch();
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = o[c] + p.cc_bias[c];
+  }
+  b = sat_round_u8(o[0]);
+  g = sat_round_u8(o[1]);
+  r = sat_round_u8(o[2]);
+}
 __device__ __forceinline__ void apply_cc(const ChainParams& p, int& b, int& g, int& r) {
   float fb = (float)b, fg = (float)g, fr = (float)r;
   float o[3];
@@ -242,19 +268,6 @@ __device__ __forceinline__ void apply_cc(const ChainParams& p, int& b, int& g, i
   b = sat_round_u8(o[0]);
   g = sat_round_u8(o[1]);
   r = sat_round_u8(o[2]);
-}
-
-// vignetting mask value at destination pixel (row, col): vignetting_correction.cpp:32-63
-__device__ __forceinline__ float vignette_mask(const ChainParams& p, int row, int col) {
-  int dx2 = 2 * col - p.dcols, dy2 = 2 * row - p.drows;
-  double s = (double)(mul24(dx2, dx2) + mul24(dy2, dy2)) * 0.25;  // exact (|dx2|, |dy2| < 2^23)
-  double s2 = s * s;
-  double k = s * p.vig_a2 + s2 * p.vig_a4;
-  float m = (float)k;
-  if (p.vig_has_max) m = m * p.vig_inv_max;
-  m = m * p.vig_scale;
-  m = m + 1.0f;
-  return m;
 }
 
 // abToXZ_b[i - minABvalue] (OpenCV color_lab.cpp initLabTabs), evaluated arithmetically.
@@ -338,6 +351,162 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
   b = tb.invg(clampi(bo, 0, 4095));
   g = tb.invg(clampi(go, 0, 4095));
   r = tb.invg(clampi(ro, 0, 4095));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lab round trip of the fast kernel (same arithmetic as apply_vignette above, re-tabulated so that the
+// per-pixel work shrinks to what cannot be tabulated):
+//  * forward 3x3 as nine v_fma_f32 whose coefficients are 32-bit literals (kLabFwd: OpenCV's fixed sRGB/D65
+//    matrix; the host refuses to start if its tables ever disagree): exact in fp32 (small integers scaled by
+//    2^-12, every partial sum below 2^24 ulps).  Literal and VGPR sources issue at the full rate (2.45 cycles per
+//    wave64), an SGPR source makes the same opcode cost 4.3 -- profiles/r02_valu_issue_rates.txt.  The same
+//    product as three v_mfma_f32_4x4x1_16B_f32 per pixel (each lane's own scalar times the four coefficients its
+//    4-lane block holds) was measured too: bit-identical, but 8.4 cycles per MFMA and no overlap with the VALU
+//    issue of the other waves, i.e. slower than the FMAs it replaces (RIP_LAB_MFMA=1 keeps it for A/B runs).
+//  * LabCbrtTab_b re-tabulated as three float tables whose entries already carry the factors and
+//    tie-breaking offsets of the L / a / b formulas: X -> 25 f + 1/8, Y -> {L, 25 f}, Z -> 25 f - 1/8, so
+//    a = RN((X - Y) * 5 / 8192) + 128 and b = RN((Y - Z) / 4096) + 128 exactly (the +-1/8 turns CV_DESCALE's
+//    round-half-up into a never-tying round-to-nearest; every table index stays <= 2040 because each
+//    forward row sums to 4096).
+//  * LabToYF_b re-tabulated per L as {ify, cy_b * y + r, cy_g * y + r, cy_r * y + r}: the y terms of the
+//    inverse matrix and its rounding constant become the accumulator of one v_dot2_i32_i16 per output
+//    channel, whose two products are the x and z terms (z is biased by kZoff to fit 16 bits; the bias is
+//    pre-multiplied into r).  Ranges (all 2^24 inputs x every L'): tests/test_oracle_known_answers.py.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// RGB2Lab_b coefficients (B, G, R columns of the X, Y, Z rows) and Lab2RGBinteger coefficients (X, Y, Z columns of
+// the B, G, R rows), lab_shift = 12: compile-time so that they reach the instructions as literals.
+// rip_api.cpp checks them against the host-built tables (make_color_tables) when a handle is created.
+constexpr int kLabFwd[9] = {778, 1541, 1777, 296, 2929, 871, 3575, 448, 73};
+constexpr int kLabInv[9] = {217, -836, 4715, -3773, 7684, 185, 12615, -6296, -2223};
+constexpr int kVigCbrtN = 2048;  // LabCbrtTab_b indices reachable from 8-bit input: 0 .. 2040
+constexpr int kZoff = 27500;     // z in [-999, 59828] -> z - kZoff fits int16
+struct VigTabs {
+  float lin[256];
+  float cbx[kVigCbrtN];
+  float2 cby[kVigCbrtN];
+  float cbz[kVigCbrtN];
+  int4 yf[256];
+  uint8_t invg[4096];
+  template <int NT>
+  __device__ __forceinline__ void load(const DevTables* t) {
+    for (int i = threadIdx.x; i < 256; i += NT) {
+      lin[i] = (float)t->lin_tab[i];
+      const uint32_t e = t->yf_tab[i];
+      const int y = (int)(e & 0xffffu);
+      int4 o;
+      o.x = (int)(e >> 16);
+#define RIP_YACC(c) (kLabInv[(c) * 3 + 1] * y + (1 << 13) + kZoff * kLabInv[(c) * 3 + 2])
+      o.y = RIP_YACC(0);
+      o.z = RIP_YACC(1);
+      o.w = RIP_YACC(2);
+#undef RIP_YACC
+      yf[i] = o;
+    }
+    for (int i = threadIdx.x; i < kVigCbrtN; i += NT) {
+      const int f = (int)t->cbrt_tab[i];
+      const float f25 = (float)(25 * f);  // <= 25 * 32768: exact
+      // L = CV_DESCALE(Lscale * fY + Lshift, lab_shift2), saturate_cast<uchar> (RGB2Lab_b)
+      const int L = clampi((296 * f - 1336934 + (1 << 14)) >> 15, 0, 255);
+      cbx[i] = f25 + 0.125f;
+      cby[i] = make_float2((float)L, f25);
+      cbz[i] = f25 - 0.125f;
+    }
+    uint32_t* d = reinterpret_cast<uint32_t*>(invg);
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(t->inv_gamma);
+    for (int i = threadIdx.x; i < 1024; i += NT) d[i] = s[i];
+  }
+};
+// per-lane constants of the round trip
+#ifndef RIP_LAB_MFMA
+#define RIP_LAB_MFMA 0
+#endif
+
+struct VigRegs {
+#if RIP_LAB_MFMA
+  float a0, a1, a2;  // MFMA A operands: lane l holds kLabFwd[(l & 3) * 3 + c] / 4096 (row 3: 0)
+#endif
+  __device__ __forceinline__ void load() {
+#if RIP_LAB_MFMA
+    const int row = (int)(threadIdx.x & 3u);
+    a0 = row == 0 ? kLabFwd[0] / 4096.0f : row == 1 ? kLabFwd[3] / 4096.0f : row == 2 ? kLabFwd[6] / 4096.0f : 0.0f;
+    a1 = row == 0 ? kLabFwd[1] / 4096.0f : row == 1 ? kLabFwd[4] / 4096.0f : row == 2 ? kLabFwd[7] / 4096.0f : 0.0f;
+    a2 = row == 0 ? kLabFwd[2] / 4096.0f : row == 1 ? kLabFwd[5] / 4096.0f : row == 2 ? kLabFwd[8] / 4096.0f : 0.0f;
+#endif
+  }
+};
+
+// Four pixels of one row through BGR -> Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93).
+__device__ __forceinline__ void vignette4(const VigTabs& tb, const VigRegs& vr, const float (&mask)[4], int (&q)[4][3]) {
+  constexpr float kMagic = 12582912.0f;         // 1.5 * 2^23: ulp 1 in [2^23, 2^24)
+  constexpr unsigned kMagicBits = 0x4B400000u;  // its bit pattern
+  unsigned ix[4], iy[4], iz[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float v0 = tb.lin[q[k][0]], v1 = tb.lin[q[k][1]], v2 = tb.lin[q[k][2]];
+    // acc_r = (C_r . v + 0.5) / 4096, exact; RN(acc_r + magic) = (C_r . v + 2048) >> 12 (never a tie)
+    f32x4 acc = {1.0f / 8192.0f, 1.0f / 8192.0f, 1.0f / 8192.0f, 0.0f};
+#if RIP_LAB_MFMA
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vr.a0, v0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vr.a1, v1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vr.a2, v2, acc, 0, 0, 0);
+#else
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      acc[r] = __builtin_fmaf(v2, (float)kLabFwd[r * 3 + 2] * (1.0f / 4096.0f),
+                              __builtin_fmaf(v1, (float)kLabFwd[r * 3 + 1] * (1.0f / 4096.0f),
+                                             __builtin_fmaf(v0, (float)kLabFwd[r * 3] * (1.0f / 4096.0f), acc[r])));
+#endif
+    ix[k] = __float_as_uint(acc[0] + kMagic) - kMagicBits;
+    iy[k] = __float_as_uint(acc[1] + kMagic) - kMagicBits;
+    iz[k] = __float_as_uint(acc[2] + kMagic) - kMagicBits;
+  }
+  int fx[4], fz[4], x[4], z[4];
+  int4 e[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float X = tb.cbx[ix[k]], Z = tb.cbz[iz[k]];
+    const float2 LY = tb.cby[iy[k]];
+    const int L = sat_round_u8(LY.x * mask[k]);  // convertTo(32F), multiply, convertTo(8U)
+    // a, b never leave [0, 255] (exhaustive test), so saturate_cast is dead; abits = kMagicBits + a
+    const unsigned abits = __float_as_uint(__builtin_fmaf(X - LY.y, 5.0f / 8192.0f, kMagic + 128.0f));
+    const unsigned bbits = __float_as_uint(__builtin_fmaf(LY.y - Z, 1.0f / 4096.0f, kMagic + 128.0f));
+    e[k] = tb.yf[L];
+    // adiv = ((5 * a * 53687 + 128) >> 13) - 128 * BASE / 500, bdiv = ((b * 41943 + 16) >> 9) - 128 * BASE / 200 + 1:
+    // the 24-bit multiply reads 0x400000 + a; the constant takes 0x400000 * K back and carries the subtrahend
+    // times 2^shift, so one multiply-add and one arithmetic shift give the signed result.
+    constexpr unsigned kA = 5u * 53687u, kB = 41943u;
+    constexpr unsigned cA = (1u << 7) - 0x400000u * kA - ((128u * 16384u / 500u) << 13);
+    constexpr unsigned cB = (1u << 4) - 0x400000u * kB - ((128u * 16384u / 200u - 1u) << 9);
+    const int adiv = (int)(__umul24(abits, kA) + cA) >> 13;
+    const int bdiv = (int)(__umul24(bbits, kB) + cB) >> 9;
+    fx[k] = e[k].x + adiv;
+    fz[k] = e[k].x - bdiv;
+    x[k] = ab_to_xz_cube(fx[k]);
+    z[k] = ab_to_xz_cube(fz[k]);
+  }
+  // abToXZ_b's linear segment (i <= 3390: L* below ~8) is rare: one wave-uniform test for the four pixels
+  const int lo = min(min(min(fx[0], fz[0]), min(fx[1], fz[1])), min(min(fx[2], fz[2]), min(fx[3], fz[3])));
+  if (__builtin_amdgcn_ballot_w64(lo <= 3390) != 0ull) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (fx[k] <= 3390) x[k] = ab_to_xz_linear(fx[k]);
+      if (fz[k] <= 3390) z[k] = ab_to_xz_linear(fz[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    // {x, z - kZoff} as int16 pair; x in [-361, 28027]
+    const i16x2 xz = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm((uint32_t)(z[k] - kZoff), (uint32_t)x[k], 0x05040100u));
+    constexpr i16x2 cb = {(short)kLabInv[0], (short)kLabInv[2]}, cg = {(short)kLabInv[3], (short)kLabInv[5]},
+                    cr = {(short)kLabInv[6], (short)kLabInv[8]};
+    const int bo = __builtin_amdgcn_sdot2(xz, cb, e[k].y, false) >> 14;
+    const int go = __builtin_amdgcn_sdot2(xz, cg, e[k].z, false) >> 14;
+    const int ro = __builtin_amdgcn_sdot2(xz, cr, e[k].w, false) >> 14;
+    q[k][0] = tb.invg[clampi(bo, 0, 4095)];
+    q[k][1] = tb.invg[clampi(go, 0, 4095)];
+    q[k][2] = tb.invg[clampi(ro, 0, 4095)];
+  }
 }
 
 // color_enhancer.cpp:38-47: RGB2HSV_b (H in [0,180)), float gain with u8 saturation,
@@ -461,27 +630,29 @@ struct Planar {
 };
 __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
 
-// Bilinear demosaic of the 4x2 tile, four pixels per instruction (SWAR): every row of the window is
-// split into its even and odd bytes, widened to 16-bit lanes inside a dword, so one v_add_u32 adds
-// two taps of two pixels and the sums (<= 4*255 + 2) cannot carry across lanes.
-// RY/RX: position of the R sample in the 2x2 cell.  out[ly] = image row y0 + ly.
-// One window row prepared for the SWAR sums: the centre dword, the two shifted views and their
-// even / odd bytes widened to 16-bit lanes.
+// Bilinear demosaic of the 4x2 tile, four pixels per instruction, entirely on v_lerp_u8
+// (D.byte = (S0.byte + S1.byte + (S2.byte & 1)) >> 1, all four bytes of a dword at once):
+//   two taps   (a + b + 1) >> 1                      = lerp(a, b, 1)
+//   four taps  (a + b + c + d + 2) >> 2              = lerp(lerp(a, b, 1), lerp(c, d, 1), ~((a ^ b) | (c ^ d)))
+// The second line is exact: with ca = (a + b + 1) >> 1, ra = (a ^ b) & 1 (likewise cb, rb) the sum is
+// 2 (ca + cb) + 2 - ra - rb, whose quarter is (ca + cb + 1) >> 1 when ra = rb = 0 and (ca + cb) >> 1 otherwise
+// (tests/test_oracle_known_answers.py checks the identity over all byte quadruples of a generating set).
+// No even/odd byte split, no widening to 16-bit lanes, and the pair averages are shared: the horizontal pair of a
+// row serves the two-tap H of that row and the diagonal four-tap of the rows above and below it.
+// One window row prepared for the demosaic: the centre dword, the two shifted views, their two-tap average and
+// their parity word.
 struct RowPrep {
-  uint32_t c, wm, wp;        // columns x0 .. x0+3, x0-1 .. x0+2, x0+1 .. x0+4
-  uint32_t hs_lo, hs_hi;     // left + right neighbour of pixels (0, 2) and (1, 3)
-  uint32_t c_lo, c_hi;       // centre bytes of pixels (0, 2) and (1, 3)
+  uint32_t c, wm, wp;  // columns x0 .. x0+3, x0-1 .. x0+2, x0+1 .. x0+4
+  uint32_t h;          // (left + right + 1) >> 1 of every pixel
+  uint32_t hx;         // left ^ right
 };
 __device__ __forceinline__ RowPrep prep_row(uint32_t left, uint32_t centre, uint32_t right) {
-  constexpr uint32_t M8 = 0x00FF00FFu;
   RowPrep r;
   r.c = centre;
   r.wm = __builtin_amdgcn_alignbyte(centre, left, 3);
   r.wp = __builtin_amdgcn_alignbyte(right, centre, 1);
-  r.hs_lo = (r.wm & M8) + (r.wp & M8);
-  r.hs_hi = ((r.wm >> 8) & M8) + ((r.wp >> 8) & M8);
-  r.c_lo = centre & M8;
-  r.c_hi = (centre >> 8) & M8;
+  r.h = __builtin_amdgcn_lerp(r.wm, r.wp, 0x01010101u);
+  r.hx = r.wm ^ r.wp;
   return r;
 }
 
@@ -489,14 +660,11 @@ __device__ __forceinline__ RowPrep prep_row(uint32_t left, uint32_t centre, uint
 // RED_ROW: the row holds R samples; RX: column parity of the R samples.
 template <bool RED_ROW, int RX>
 __device__ __forceinline__ Planar debayer_row(const RowPrep& up, const RowPrep& at, const RowPrep& dn) {
-  constexpr uint32_t M8 = 0x00FF00FFu;
   constexpr uint32_t kEven = RX == 0 ? 0x00FF00FFu : 0xFF00FF00u;  // byte lanes with dx == 0
-  // two-tap averages (a + b + 1) >> 1 of all four byte lanes in one v_lerp_u8
-  const uint32_t H = __builtin_amdgcn_lerp(at.wm, at.wp, 0x01010101u);
+  const uint32_t H = at.h;
   const uint32_t V = __builtin_amdgcn_lerp(up.c, dn.c, 0x01010101u);
-  const uint32_t X4 = (((at.hs_lo + up.c_lo + dn.c_lo + 0x00020002u) >> 2) & M8) |
-                      ((((at.hs_hi + up.c_hi + dn.c_hi + 0x00020002u) >> 2) & M8) << 8);
-  const uint32_t D4 = (((up.hs_lo + dn.hs_lo + 0x00020002u) >> 2) & M8) | ((((up.hs_hi + dn.hs_hi + 0x00020002u) >> 2) & M8) << 8);
+  const uint32_t X4 = __builtin_amdgcn_lerp(H, V, ~(at.hx | (up.c ^ dn.c)));     // left, right, up, down
+  const uint32_t D4 = __builtin_amdgcn_lerp(up.h, dn.h, ~(up.hx | dn.hx));       // the four diagonal neighbours
   const uint32_t C = at.c;
   Planar o;
   if (RED_ROW) {
@@ -513,9 +681,6 @@ __device__ __forceinline__ Planar debayer_row(const RowPrep& up, const RowPrep& 
   return o;
 }
 
-// Bilinear demosaic of the 4x2 tile, four pixels per instruction (SWAR): every row of the window is
-// split into its even and odd bytes, widened to 16-bit lanes inside a dword, so one v_add_u32 adds
-// two taps of two pixels and the sums (<= 4*255 + 2) cannot carry across lanes.
 // RY/RX: position of the R sample in the 2x2 cell.  out[ly] = image row y0 + ly; r[k] = row y0 - 1 + k.
 template <int RY, int RX>
 __device__ __forceinline__ void debayer_rows(const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3,
@@ -534,6 +699,9 @@ __device__ __forceinline__ void debayer_swar(const Window& win, Planar (&out)[2]
 // OpenCV's border replication on a demosaiced 4x2 tile: column 0 := column 1, column W-1 := W-2,
 // then row 0 := row 1, row H-1 := H-2
 __device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int cols, Planar (&out)[2]) {
+  // interior items (all but a 1 / (rows / 2) + 1 / (cols / 4) fraction) skip all of it behind one wave-uniform test
+  const bool edge = x0 == 0 || x0 + 4 == cols || y0 == 0 || y0 + 2 == rows;
+  if (__builtin_amdgcn_ballot_w64(edge) == 0ull) return;
   if (x0 == 0) {
 #pragma unroll
     for (int ly = 0; ly < 2; ly++) {
@@ -675,13 +843,16 @@ bool bayer_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, i
          (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
 }
 
-// grid-size tunables (persistent workgroups per launch), overridable from the environment for experiments
-int tune_env(const char* name, int dflt) {
+// launch tunables, overridable from the environment for experiments.  tune_grid: persistent workgroups per launch,
+// always a multiple of 8 and at least 8 (the kernels give every XCD its own share and stride by gridDim.x / 8);
+// tune_int: any other positive integer (frames per visit, ring stages, workgroups per CU).
+int tune_int(const char* name, int dflt) {
   const char* e = std::getenv(name);
   if (!e || !*e) return dflt;
   const int v = std::atoi(e);
-  return v >= 8 ? v / 8 * 8 : (v > 0 ? v : dflt);
+  return v > 0 ? v : dflt;
 }
+int tune_grid(const char* name, int dflt) { return std::max(8, tune_int(name, dflt) / 8 * 8); }
 
 }  // namespace
 }  // namespace rip

@@ -525,41 +525,46 @@ const ColorTables& color_tables() {
 // ---------------------------------------------------------------------------------------------
 // Vignetting
 // ---------------------------------------------------------------------------------------------
-namespace {
-inline double vignette_k(double a2, double a4, int rows, int cols, int row, int col) {
-  // s = (col - cols/2)^2 + (row - rows/2)^2, exact: 4s is an integer < 2^31
-  long long dx2 = 2LL * col - cols, dy2 = 2LL * row - rows;
-  double s = (double)(dx2 * dx2 + dy2 * dy2) * 0.25;
-  double s2 = s * s;
-  return s * a2 + s2 * a4;
-}
-}  // namespace
-
-VignetteConst build_vignette_const(int rows, int cols, double scale, double a2, double a4) {
-  VignetteConst c;
-  c.a2 = a2;
-  c.a4 = a4;
-  c.scale = (float)scale;
-  // max over the image of float(k): k depends on (|2col-cols|, |2row-rows|) only
+// vignetting_correction.cpp:32-63, operation by operation: r = sqrt(pow(dy, 2) + pow(dx, 2)) in double,
+// k = pow(r, 2) * a2 + pow(r, 4) * a4, stored as float; mask = k / max (x float(1 / max)), x float(scale), + 1.0f.
+// The same libm the reference would call does the work (the sqrt -> pow detour matters: with a2 = 1e-3, a4 = 1e-6
+// k lands on float rounding ties often enough that the algebraically equal s * a2 + s^2 * a4 differs in ~1e-3 of
+// the pixels).  k depends on (|row - rows/2|, |col - cols/2|) only, so one quadrant is evaluated and mirrored --
+// the per-pixel operands are identical, only the number of pow() calls drops.  Once per (geometry, parameters);
+// the reference rebuilds it on every non-square frame (quirk Q6).
+void build_vignette_mask(int rows, int cols, double scale, double a2, double a4, std::vector<float>& mask) {
+  mask.resize((size_t)rows * cols);
+  const double cy = rows / 2.0, cx = cols / 2.0;
+  // distinct |2 * d| values per axis: index = |2 * i - n|
+  std::vector<float> quad((size_t)(rows + 1) * (cols + 1), 0.f);
+  std::vector<char> have((size_t)(rows + 1) * (cols + 1), 0);
   float mx = -FLT_MAX;
   for (int row = 0; row < rows; row++) {
+    const int ay = std::abs(2 * row - rows);
     for (int col = 0; col < cols; col++) {
-      float kf = (float)vignette_k(a2, a4, rows, cols, row, col);
+      const int ax = std::abs(2 * col - cols);
+      const size_t qi = (size_t)ay * (cols + 1) + ax;
+      if (!have[qi]) {
+        const double dy = std::fabs(row - cy), dx = std::fabs(col - cx);
+        const double r = std::sqrt(std::pow(dx, 2) + std::pow(dy, 2));
+        const double k = std::pow(r, 2) * a2 + std::pow(r, 4) * a4;
+        quad[qi] = (float)k;
+        have[qi] = 1;
+      }
+      const float kf = quad[qi];
+      mask[(size_t)row * cols + col] = kf;
       if (kf > mx) mx = kf;
     }
   }
-  double maxv = (double)mx;
-  c.has_max = maxv > 0 ? 1 : 0;
-  c.inv_max = c.has_max ? (float)(1.0 / maxv) : 1.f;
-  return c;
-}
-
-float vignette_mask_value(const VignetteConst& c, int rows, int cols, int row, int col) {
-  float m = (float)vignette_k(c.a2, c.a4, rows, cols, row, col);
-  if (c.has_max) m = m * c.inv_max;
-  m = m * c.scale;
-  m = m + 1.0f;
-  return m;
+  const double maxv = (double)mx;
+  const size_t n = mask.size();
+  if (maxv > 0) {
+    const float inv = (float)(1.0 / maxv);
+    for (size_t i = 0; i < n; i++) mask[i] = mask[i] * inv;
+  }
+  const float sc = (float)scale;
+  for (size_t i = 0; i < n; i++) mask[i] = mask[i] * sc;
+  for (size_t i = 0; i < n; i++) mask[i] = mask[i] + 1.0f;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -111,16 +111,9 @@ struct ColorTables {
 };
 const ColorTables& color_tables();  // built once
 
-// vignetting_correction.cpp:32-63: the mask is a closed form of (row, col); the kernel
-// evaluates it per pixel and needs only these constants.
-struct VignetteConst {
-  double a2 = 0, a4 = 0;  // k = s*a2 + s*s*a4, s = (col-cols/2)^2 + (row-rows/2)^2
-  float inv_max = 1.f;    // (float)(1.0 / max(mask)) ; has_max = max > 0
-  float scale = 1.f;
-  int has_max = 0;
-};
-VignetteConst build_vignette_const(int rows, int cols, double scale, double a2, double a4);
-float vignette_mask_value(const VignetteConst& c, int rows, int cols, int row, int col);  // host mirror
+// vignetting_correction.cpp:32-63: the float mask plane (rows x cols, tightly packed), evaluated with the
+// reference's operation order (sqrt, pow(r, 2), pow(r, 4) in double); uploaded once per geometry / parameter set
+void build_vignette_mask(int rows, int cols, double scale, double a2, double a4, std::vector<float>& mask);
 
 // ---------------------------------------------------------------------------------------------
 // Fisheye undistortion (undistortion.cpp:197-238 -> OpenCV 4.2 calib3d/fisheye.cpp), double

@@ -84,9 +84,7 @@ struct ChainParams {
   const FrameWb* wb;  // [n_frames]
   int stage_bits;     // StageBits
   float cc_m[9], cc_bias[3];
-  double vig_a2, vig_a4;
-  float vig_inv_max, vig_scale;
-  int vig_has_max;
+  const float* vig_mask;  // [drows][dcols] vignetting mask plane (vignetting_correction.cpp:32-63), ST_VIG only
   float hsv_gain[3];  // applied to H, S, V
   const DevTables* tabs;
 };

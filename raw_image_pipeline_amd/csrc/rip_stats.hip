@@ -392,7 +392,7 @@ void launch_stats(const StatsParams& p, hipStream_t stream) {
     const int col_waves = (groups + 63) / 64;
     // per frame: 512 wave tasks when the batch fills the chip anyway, at most 1024 for a single frame (more
     // tasks only queue up on the three 64-bit atomics every workgroup ends with: 22 -> 12.6 us for one frame)
-    const int budget = tune_env("RIP_STATS_BLOCKS", 2048) * 4;
+    const int budget = tune_grid("RIP_STATS_BLOCKS", 2048) * 4;
     const int target_tasks = std::max(8, std::min(budget / 8, budget / std::max(1, std::min(p.n_frames, 16))));
     int pairs_per_task = std::max(2, (int)(((long long)col_waves * n_pairs + target_tasks - 1) / target_tasks));
     pairs_per_task = std::min((pairs_per_task + 1) & ~1, 128);  // even: the kernel consumes two pairs per iteration

@@ -469,6 +469,13 @@ class RawImagePipeline:
         self._call("rip_profile_end", ms, cnt)
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
 
+    def get_vignetting_mask(self, rows, cols):
+        """Host-built mask plane of precomputeVignettingMask (vignetting_correction.cpp:32-63)."""
+        out = np.empty((int(rows), int(cols)), np.float32)
+        self._check(self._lib.rip_get_vignetting_mask(self._h, int(rows), int(cols), out.ctypes.data_as(C.c_void_p),
+                                                      C.c_size_t(out.size)))
+        return out
+
     def get_table(self, which):
         buf = np.empty(4096, np.int32)
         n = self._lib.rip_get_table(self._h, int(which), buf.ctypes.data_as(C.c_void_p), 4096)

@@ -205,3 +205,17 @@ def test_yaml_flow_maps_and_any_key_order(tmp_path):
     bad.write_text("matrix: {rows: 3, cols: 3, data: [1, 0, 0\n")
     with pytest.raises(RipIOError):
         p.load_color_calibration(str(bad))
+
+
+@pytest.mark.parametrize("rows,cols", [(2048, 2448), (2160, 3840), (1200, 1920), (480, 640), (97, 131), (64, 64), (3, 5)])
+def test_vignetting_mask_plane_equals_the_reference_formula_bit_for_bit(host_pipe, oracle, rows, cols):
+    """The product's mask plane (host, quadrant-mirrored) against the oracle's literal restatement of
+    precomputeVignettingMask (vignetting_correction.cpp:32-63: sqrt, pow(r, 2), pow(r, 4), /max, *scale, +1):
+    every float identical, including the sizes where the algebraically equal s*a2 + s^2*a4 differs (2448x2048:
+    ~830 floats, 3840x2160: L values flip)."""
+    for scale, a2, a4 in ((1.5, 1e-3, 1e-6), (0.7, 3.3e-4, -2.0e-7), (1.0, 0.0, 0.0)):
+        host_pipe.set_vignetting_correction_parameters(scale, a2, a4)
+        got = host_pipe.get_vignetting_mask(rows, cols)
+        want = oracle.vignetting_mask(rows, cols, scale, a2, a4)
+        assert got.shape == want.shape == (rows, cols)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
