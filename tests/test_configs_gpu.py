@@ -1,0 +1,130 @@
+"""BASELINE.json configs[3] and configs[4] on ONE GPU, and the multi-rank bench rehearsal.
+
+configs[3] ("8-camera Alphasense rig, 8 concurrent 2448x2048 streams") shards cameras over GPUs with no data-path
+collective, so its correctness content is: eight independent handles (own tables, maps, mask plane, ccc Kalman state),
+each on its own HIP stream, running concurrently, every frame equal to the oracle.  That runs on one device.
+configs[4] (3840x2160, 512-frame batch over 8 GPUs = 64 resident frames per GPU) is exercised at its per-GPU batch."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from raw_image_pipeline_amd import synth
+
+from helpers import assert_images_equal, cfg, configure, oracle_run
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config4_rig_of_8_cameras_2448x2048_on_one_device(rip_lib, oracle):
+    """Eight CameraStreams (the ROS node's counterpart: one handle + one HIP stream per camera, camera c -> device
+    c mod n_devices, here n_devices = 1), full chain at 2448x2048, different parameters per camera, two of them on the
+    ccc estimator with temporal consistency and different tint drifts.  All batches are enqueued before any
+    synchronisation.  Every frame of every camera must equal the oracle run with that camera's parameters and -- for
+    ccc -- that camera's own filter state: a leak of tables, mask, maps or Kalman state between handles shows up."""
+    import torch
+    from raw_image_pipeline_amd.frontend import CameraRig
+    w, h, ncam, nframes = 2448, 2048, 8, 2
+    filt, bias = synth.ccc_model()
+    rig = CameraRig([{"output_prefix": "/alphasense/cam%d" % c} for c in range(ncam)], n_devices=1, ccc_model=(filt, bias))
+    assert len({s.cuda_stream for s in rig.hip_streams}) == ncam
+    cams = []
+    for c in range(ncam):
+        ccc = c in (2, 5)
+        conf = cfg(flip=True, flip_angle=180 if c % 2 == 0 else 0, wb=True, wb_method="ccc" if ccc else ("grey_world" if c % 3 else "pca"),
+                   wb_temporal=ccc, cc=True, gamma=True, gamma_k=0.7 + 0.05 * c, vig=True, vig_params=(1.5 - 0.1 * c, 1e-3, 1e-6),
+                   undistort=True, cam=synth.camera_model(w, h), balance=0.1 * (c % 3))
+        configure(rig.streams[c].pipe, conf)
+        if ccc:
+            rig.streams[c].pipe.set_ccc_kalman_model(1.0, 10.0)
+            rig.streams[c].reset_white_balance()
+        drift = 0.04 if c == 2 else -0.05
+        frames = np.stack([synth.gen_frame(w, h, "bayer_rggb8", seed=1000 * c + i, kind="scene",
+                                           tint=(0.70 + drift * i, 1.0, 0.55 + 0.01 * c)) for i in range(nframes)])
+        cams.append((conf, frames, ccc))
+    batches = [torch.from_numpy(f).cuda() for _, f, _ in cams]
+    torch.cuda.synchronize()
+    outs = rig.process_resident(batches, ["bayer_rggb8"] * ncam)  # asynchronous: eight streams in flight
+    rig.synchronize()
+    info = {c: rig.streams[c].pipe.get_white_balance_info(nframes) for c in (2, 5)}
+    for c, (conf, frames, ccc) in enumerate(cams):
+        occ = None
+        if ccc:
+            occ = oracle.CCC(filt, bias)
+            occ.set_kalman_model(1.0, 10.0)
+        got = outs[c].cpu().numpy()
+        for i in range(nframes):
+            ref, _ = oracle_run(oracle, conf, frames[i], "bayer_rggb8", ccc=occ)
+            assert_images_equal(got[i], ref, "camera %d frame %d" % (c, i))
+    # the two ccc cameras saw opposite drifts: their filtered (u, v) tracks must differ (state is per handle)
+    assert not np.array_equal(info[2][:, 6:8], info[5][:, 6:8])
+
+
+def test_config5_batch_of_64_resident_4k_frames(gpu_pipe, oracle):
+    """BASELINE configs[4] at its per-GPU share: 64 resident 3840x2160 rggb8 frames through apply_device, debayer +
+    undistortion.  Frame 0 is checked against the oracle; every frame must equal the single-frame result of its source
+    frame (the batch kernels walk frames innermost and split the batch into groups: no cross-talk, no missed frame)."""
+    import torch
+    w, h, n, distinct = 3840, 2160, 64, 4
+    c = cfg(undistort=True, cam=synth.camera_model(w, h))
+    configure(gpu_pipe, c)
+    base = [synth.gen_frame(w, h, "bayer_rggb8", seed=5 + i, kind="scene" if i % 2 == 0 else "uniform") for i in range(distinct)]
+    singles = [gpu_pipe.process(f, "bayer_rggb8") for f in base]
+    ref, _ = oracle_run(oracle, c, base[0], "bayer_rggb8")
+    assert_images_equal(singles[0], ref, "config5 single frame vs oracle")
+    dev = torch.from_numpy(np.stack(base)).cuda()
+    order = (torch.arange(n, device="cuda") * 7 + 3) % distinct  # not a plain repeat pattern
+    batch = dev[order].contiguous()
+    out = gpu_pipe.apply_device(batch, "bayer_rggb8")
+    torch.cuda.synchronize()
+    assert out.shape == (n, h, w, 3)
+    expect = torch.from_numpy(np.stack(singles)).cuda()
+    order = order.cpu().numpy()
+    for i in range(n):
+        assert torch.equal(out[i], expect[order[i]]), "batch frame %d (source %d) differs from its single-frame result" % (i, order[i])
+
+
+def test_config2_batch_of_64_resident_frames_full_chain(gpu_pipe, oracle):
+    """BASELINE configs[1] with the 64 resident frames it names: every frame of the batch equals the single-frame
+    result (frame 0 also the oracle), taps included."""
+    import torch
+    from helpers import cfg as _cfg
+    w, h, n, distinct = 2448, 2048, 64, 4
+    c = _cfg(flip=True, flip_angle=180, wb=True, wb_method="grey_world", cc=True, gamma=True, gamma_k=0.8, vig=True, undistort=True,
+             cam=synth.camera_model(w, h))
+    configure(gpu_pipe, c)
+    base = [synth.gen_frame(w, h, "bayer_rggb8", seed=300 + i, kind="scene", tint=(0.6 + 0.05 * i, 1.0, 0.5)) for i in range(distinct)]
+    singles = [gpu_pipe.process(f, "bayer_rggb8") for f in base]
+    ref, _ = oracle_run(oracle, c, base[0], "bayer_rggb8")
+    assert_images_equal(singles[0], ref, "config2 single frame vs oracle")
+    dev = torch.from_numpy(np.stack(base)).cuda()
+    order = (torch.arange(n, device="cuda") * 5 + 1) % distinct
+    out = gpu_pipe.apply_device(dev[order].contiguous(), "bayer_rggb8")
+    torch.cuda.synchronize()
+    expect = torch.from_numpy(np.stack(singles)).cuda()
+    order = order.cpu().numpy()
+    for i in range(n):
+        assert torch.equal(out[i], expect[order[i]]), "batch frame %d differs" % i
+
+
+def test_bench_two_rank_rehearsal_prints_one_json_line():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on a 1-GPU box
+    with RIP_BENCH_BACKEND=gloo (both ranks share device 0): exactly one JSON line, from rank 0, with n_gpus = 2, the
+    whole-job frame count and the scatter record of the N > 1 path."""
+    env = dict(os.environ, RIP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", "--no-hbm-probe"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["frames_per_step_per_gpu"] == 8
+    assert abs(j["value"] - 2 * 8 * 2 / (j["ms_per_step"] * 2 * 1e-3)) / j["value"] < 1e-3  # whole-job frames / max-over-ranks time
+    assert j["scatter"]["ranks"] == 2 and j["scatter"]["frames_per_destination"] > 0 and j["scatter"]["GBps_per_destination"] > 0
