@@ -86,6 +86,11 @@ rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, 
 /* Geometry/encoding rip_apply would produce for such an input (no device work). */
 rip_status rip_query_output(rip_pipeline* p, int rows, int cols, int channels, const char* encoding,
                             int* out_rows, int* out_cols, int* out_channels, char encoding_out[32]);
+/* Geometry of the two tap images for such an input: the post-flip debayered image (flip.cpp:60-62, what
+ * getDistDebayeredImage returns) and the pre-undistortion colour image (undistortion.cpp:247-249) share it;
+ * rows * cols * channels tightly packed bytes per frame is what rip_apply_device writes to each tap buffer. */
+rip_status rip_query_taps(rip_pipeline* p, int rows, int cols, int channels, const char* encoding,
+                          int* tap_rows, int* tap_cols, int* tap_channels);
 
 /* Device-resident, batched form of apply(): n_frames consecutive frames of THIS stream,
  * already in HBM (frame f at d_in + f*in_frame_stride, rows of in_step bytes), results to

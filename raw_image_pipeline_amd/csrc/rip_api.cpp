@@ -66,6 +66,21 @@ struct DevBuf {
   }
 };
 
+// Selects the handle's device for the duration of one C-ABI call and puts the caller's current device back afterwards
+// (a CameraRig thread, or torch, keeps its own current device across calls into handles that live elsewhere).
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    HIP_CHECK(hipSetDevice(device));
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct HostImage {
   std::vector<uint8_t> data;
   int rows = 0, cols = 0, channels = 0;
@@ -444,7 +459,7 @@ Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const st
 // Enqueues the whole chain for n frames.  d_out rows of out_step bytes.  Taps may be null.
 void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_step, size_t in_frame_stride, int n, int rows,
                int cols, uint8_t* d_out, size_t out_step, size_t out_frame_stride, uint8_t* d_tap_deb, uint8_t* d_tap_col) {
-  HIP_CHECK(hipSetDevice(p->device));
+  DeviceGuard device_guard(p->device);
   ensure_tables(p);
   const size_t tap_pitch = (size_t)pl.mid_cols * pl.channels;  // taps are tightly packed API outputs
   const size_t tap_frame = tap_pitch * pl.mid_rows;
@@ -626,7 +641,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     }
     if (!done) {
       ProfScope ps(p, RIP_KERNEL_REMAP);
-      rip::launch_remap(r, p->stream);
+      if (!rip::launch_remap(r, p->stream)) throw InvalidArgument("undistortion: frame geometry exceeds the kernels' 32-bit addressing");
     }
   }
   hipError_t le = hipGetLastError();
@@ -776,6 +791,18 @@ rip_status rip_query_output(rip_pipeline* p, int rows, int cols, int channels, c
   });
 }
 
+rip_status rip_query_taps(rip_pipeline* p, int rows, int cols, int channels, const char* encoding, int* tap_rows, int* tap_cols,
+                          int* tap_channels) {
+  return guarded(p, [&] {
+    need(p);
+    if (!encoding) throw InvalidArgument("encoding is null");
+    Plan pl = make_plan(p, rows, cols, channels, encoding);
+    if (tap_rows) *tap_rows = pl.mid_rows;
+    if (tap_cols) *tap_cols = pl.mid_cols;
+    if (tap_channels) *tap_channels = pl.channels;
+  });
+}
+
 rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, size_t in_frame_stride, int n_frames, int rows,
                             int cols, int channels, const char* encoding, void* d_out, size_t out_step,
                             size_t out_frame_stride, void* d_tap_debayered, void* d_tap_color) {
@@ -793,6 +820,14 @@ rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, s
     constexpr int kMaxFramesPerLaunch = 16384;
     const size_t o_step = out_step ? out_step : (size_t)pl.out_cols * pl.channels;
     const size_t o_stride = out_frame_stride ? out_frame_stride : o_step * pl.out_rows;
+    // the kernels address one frame with 32-bit byte offsets and 24-bit row multiplies: refuse pitches they cannot
+    // express (and pitches that would make rows or frames overlap) instead of writing somewhere else
+    if (o_step < (size_t)pl.out_cols * pl.channels) throw InvalidArgument("output row pitch smaller than a row");
+    if (o_stride < o_step * (size_t)pl.out_rows) throw InvalidArgument("output frame stride smaller than a frame");
+    if (in_frame_stride < in_step * (size_t)(rows - 1) + (size_t)cols * channels) throw InvalidArgument("input frame stride smaller than a frame");
+    if (in_step >= (1u << 24) || o_step >= (1u << 24) || (unsigned long long)in_step * rows >= (1ull << 32) ||
+        (unsigned long long)o_step * pl.out_rows >= (1ull << 32))
+      throw InvalidArgument("row pitch too large: pitches must stay below 16 MiB and a frame below 4 GiB");
     const size_t tap_frame = (size_t)pl.mid_rows * pl.mid_cols * pl.channels;
     for (int f0 = 0; f0 < n_frames; f0 += kMaxFramesPerLaunch) {
       const int n = std::min(kMaxFramesPerLaunch, n_frames - f0);
@@ -811,7 +846,7 @@ rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, 
     need_device(p);
     if (!image || !out || !encoding) throw InvalidArgument("null buffer or encoding");
     Plan pl = make_plan(p, rows, cols, channels, encoding);
-    HIP_CHECK(hipSetDevice(p->device));
+    DeviceGuard device_guard(p->device);
     if (step == 0) step = (size_t)cols * channels;
     const size_t in_pitch = ((size_t)cols * channels + 3) & ~(size_t)3;  // dword-aligned rows on the device
     const size_t in_bytes = in_pitch * rows;
@@ -870,7 +905,7 @@ rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_ca
     if (!out) return;  // size query
     if (out_capacity < bytes) throw CapacityError("image buffer too small");
     need_device(p);
-    HIP_CHECK(hipSetDevice(p->device));
+    DeviceGuard device_guard(p->device);
     HIP_CHECK(hipMemcpyAsync(out, p->last_buf[which]->ptr, bytes, hipMemcpyDeviceToHost, p->stream));
     HIP_CHECK(hipStreamSynchronize(p->stream));
   });
@@ -889,7 +924,20 @@ rip_status rip_load_params(rip_pipeline* p, const char* path) {
     need(p);
     if (!path) throw InvalidArgument("path is null");
     std::fprintf(stderr, "Loading raw_image_pipeline params from file %s\n", path);
-    if (!rip::load_params_file(p->m, path)) std::fprintf(stderr, "Warning: parameters file doesn't exist\n");
+    if (!rip::load_params_file(p->m, path)) {
+      std::fprintf(stderr, "Warning: parameters file doesn't exist\n");  // nothing else happens (:162-164)
+    } else {
+      // loadParams re-creates every module (std::make_unique, raw_image_pipeline.cpp:56-160): whatever
+      // loadColorCalibration / loadCameraCalibration had loaded is gone (identity matrix, calibration not available --
+      // the constructors reload them afterwards, :27-29), and the white balancer starts over with a fresh ccc
+      // estimator (first frame, new Kalman filter)
+      const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      for (int i = 0; i < 9; i++) p->m.cc_matrix[i] = (float)eye[i];
+      for (int i = 0; i < 4; i++) p->m.cc_bias[i] = 0;
+      p->m.cc_available = false;
+      p->m.und_available = false;
+      p->ccc_state_init = false;
+    }
     p->tabs_dirty = p->vig_dirty = p->ccc_cfg_dirty = true;
     und_init(p);  // setBalance / setFovScale re-run init()
   });
@@ -917,7 +965,7 @@ rip_status rip_init_undistortion(rip_pipeline* p) {
     und_init(p);
     ensure_host_maps(p);
     if (p->device != RIP_DEVICE_NONE) {
-      HIP_CHECK(hipSetDevice(p->device));
+      DeviceGuard device_guard(p->device);
       ensure_maps(p);
     }
   });
@@ -1094,7 +1142,7 @@ rip_status rip_get_white_balance_info(rip_pipeline* p, float* out, int n_frames)
     if (!out || n_frames <= 0) throw InvalidArgument("bad arguments");
     if (n_frames > p->last_batch_frames || !p->d_wb.ptr) throw InvalidArgument("no white-balance results for that many frames");
     need_device(p);
-    HIP_CHECK(hipSetDevice(p->device));
+    DeviceGuard device_guard(p->device);
     std::vector<rip::FrameWb> h(n_frames);
     HIP_CHECK(hipMemcpyAsync(h.data(), p->d_wb.ptr, sizeof(rip::FrameWb) * n_frames, hipMemcpyDeviceToHost, p->stream));
     HIP_CHECK(hipStreamSynchronize(p->stream));
@@ -1110,7 +1158,7 @@ rip_status rip_get_white_balance_info(rip_pipeline* p, float* out, int n_frames)
 rip_status rip_profile_begin(rip_pipeline* p, int max_records) {
   return guarded(p, [&] {
     need_device(p);
-    HIP_CHECK(hipSetDevice(p->device));
+    DeviceGuard device_guard(p->device);
     if (max_records < 0) throw InvalidArgument("negative record count");
     while (p->prof_events.size() < (size_t)max_records * 2) {
       hipEvent_t e;
@@ -1126,7 +1174,7 @@ rip_status rip_profile_begin(rip_pipeline* p, int max_records) {
 rip_status rip_profile_end(rip_pipeline* p, double ms_sum[RIP_KERNEL_COUNT], int count[RIP_KERNEL_COUNT]) {
   return guarded(p, [&] {
     need_device(p);
-    HIP_CHECK(hipSetDevice(p->device));
+    DeviceGuard device_guard(p->device);
     HIP_CHECK(hipStreamSynchronize(p->stream));
     for (int i = 0; i < RIP_KERNEL_COUNT; i++) {
       if (ms_sum) ms_sum[i] = 0;

@@ -166,7 +166,8 @@ void launch_ccc_estimate(const CccParams& p, hipStream_t stream);
 void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
                         const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream,
                         const unsigned* simple_hist = nullptr, float simple_p = 0.f, int simple_total = 0);
-void launch_remap(const RemapParams& p, hipStream_t stream);
+// Returns false (and launches nothing) when a pitch or frame size exceeds the kernels' 32-bit addressing.
+bool launch_remap(const RemapParams& p, hipStream_t stream);
 // Which code path launch_chain would pick (for tests / DESIGN.md): 1 fast, 0 generic.
 int chain_uses_fast_path(const ChainParams& p);
 // bgr8 / rgb8 frames that qualify for the 4-px-per-lane colour kernels (rip_chain.hip)

@@ -510,12 +510,12 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
   return true;
 }
 
-void launch_remap(const RemapParams& p, hipStream_t stream) {
-  if (p.n_frames <= 0) return;
+bool launch_remap(const RemapParams& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return true;
   // remap_pixel addresses a source frame with 32-bit offsets and 24-bit multiplies
   if (p.src_step >= (1u << 24) || p.rows >= (1 << 23) || (unsigned long long)p.src_step * (unsigned long long)p.rows >= (1ull << 32) ||
       p.dst_step >= (1u << 24) || (unsigned long long)p.dst_step * (unsigned long long)p.drows >= (1ull << 32))
-    return;  // rejected by the API layer before we get here (see rip_api.cpp make_plan)
+    return false;  // the API layer turns this into RIP_ERR_INVALID_ARGUMENT (it rejects such pitches up front)
   const bool vec = p.channels == 3 && p.dcols % 4 == 0 && p.dst_step % 4 == 0 && p.dst_frame_stride % 4 == 0 &&
                    aligned4(p.dst) && (reinterpret_cast<uintptr_t>(p.map_xy) & 15u) == 0;
   if (vec) {
@@ -523,7 +523,7 @@ void launch_remap(const RemapParams& p, hipStream_t stream) {
     const int items = p.drows * (p.dcols / 4);
     int per_frame = grid_blocks_for(items, std::max(8, 8192 / std::max(1, std::min(p.n_frames, 16))));
     hipLaunchKernelGGL(remap_vec4_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
-    return;
+    return true;
   }
   long long npix = (long long)p.drows * p.dcols;
   dim3 grid(grid_blocks_for(npix, 4096), p.n_frames);
@@ -531,6 +531,7 @@ void launch_remap(const RemapParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(remap_generic_kernel<3>, grid, dim3(kBlock), 0, stream, p);
   else
     hipLaunchKernelGGL(remap_generic_kernel<1>, grid, dim3(kBlock), 0, stream, p);
+  return true;
 }
 
 }  // namespace rip

@@ -92,6 +92,7 @@ class RawImagePipeline:
             self._h = C.c_void_p()
             self._raise(st, msg)
         self.device = int(device)
+        self._torch_stream = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -121,6 +122,7 @@ class RawImagePipeline:
 
     def set_stream(self, stream):
         """HIP stream handle (int / torch.cuda.Stream) the device work is enqueued on."""
+        self._torch_stream = stream if hasattr(stream, "wait_stream") else None
         handle = getattr(stream, "cuda_stream", stream)
         self._call("rip_set_stream", C.c_void_p(int(handle) if handle else 0))
 
@@ -183,13 +185,31 @@ class RawImagePipeline:
             out = torch.empty(shape, dtype=torch.uint8, device=frames.device)
         elif tuple(out.shape) != shape or not out.is_contiguous():
             raise ValueError("out must be a contiguous tensor of shape %s" % (shape,))
-        for t in (tap_debayered, tap_color):
-            if t is not None and (not t.is_contiguous() or t.dtype != torch.uint8):
-                raise ValueError("tap tensors must be contiguous uint8")
-        self._call("rip_apply_device", C.c_void_p(frames.data_ptr()), C.c_size_t(in_step), C.c_size_t(in_frame), int(n),
-                   int(rows), int(cols), int(cn), encoding.encode(), C.c_void_p(out.data_ptr()), C.c_size_t(0),
-                   C.c_size_t(0), C.c_void_p(tap_debayered.data_ptr() if tap_debayered is not None else 0),
-                   C.c_void_p(tap_color.data_ptr() if tap_color is not None else 0))
+        if out.device != frames.device:
+            raise ValueError("out must live on the device of frames")
+        # taps hold the post-flip, pre-undistortion geometry (tightly packed): query it with undistortion off
+        if tap_debayered is not None or tap_color is not None:
+            tr, tc, tcn = C.c_int(), C.c_int(), C.c_int()
+            self._call("rip_query_taps", int(rows), int(cols), int(cn), encoding.encode(), C.byref(tr), C.byref(tc), C.byref(tcn))
+            tshape = (n, tr.value, tc.value) if tcn.value == 1 else (n, tr.value, tc.value, tcn.value)
+            for t in (tap_debayered, tap_color):
+                if t is not None and (t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != tshape
+                                      or t.device != frames.device):
+                    raise ValueError("tap tensors must be contiguous uint8 CUDA tensors of shape %s" % (tshape,))
+        # The C call enqueues on the handle's stream; the tensors were produced / allocated on torch's current stream.
+        # Order the two when they differ, and tell the caching allocator that the handle's stream uses the buffers.
+        cur = torch.cuda.current_stream(frames.device)
+        mine = self._torch_stream
+        if mine is not None and mine.cuda_stream != cur.cuda_stream:
+            mine.wait_stream(cur)
+            for t in (frames, out, tap_debayered, tap_color):
+                if t is not None:
+                    t.record_stream(mine)
+        with torch.cuda.device(frames.device):  # the C-ABI selects the handle's device; keep the caller's current device
+            self._call("rip_apply_device", C.c_void_p(frames.data_ptr()), C.c_size_t(in_step), C.c_size_t(in_frame), int(n),
+                       int(rows), int(cols), int(cn), encoding.encode(), C.c_void_p(out.data_ptr()), C.c_size_t(0),
+                       C.c_size_t(0), C.c_void_p(tap_debayered.data_ptr() if tap_debayered is not None else 0),
+                       C.c_void_p(tap_color.data_ptr() if tap_color is not None else 0))
         self.last_encoding = enc
         return out
 

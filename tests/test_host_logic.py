@@ -219,3 +219,22 @@ def test_vignetting_mask_plane_equals_the_reference_formula_bit_for_bit(host_pip
         want = oracle.vignetting_mask(rows, cols, scale, a2, a4)
         assert got.shape == want.shape == (rows, cols)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_load_params_recreates_the_modules_like_the_reference(host_pipe):
+    """RawImagePipeline::loadParams (raw_image_pipeline.cpp:44-165) builds every module anew when the file exists: a colour
+    or camera calibration loaded before is gone afterwards (the constructors reload them after loadParams, :27-29); a
+    missing params file changes nothing."""
+    p = host_pipe
+    p.load_color_calibration(os.path.join(CFG, "color_calib.yaml"))
+    p.load_camera_calibration(os.path.join(CFG, "calib_64x48.yaml"))
+    m_before = p.get_color_calibration_matrix().copy()
+    assert not np.array_equal(m_before, np.eye(3))
+    p.set_undistortion(True)
+    assert p.query_output(40, 56, 1, "mono8")[:2] == (48, 64)      # remap to the calibration's size
+    p.load_params("/nonexistent/params.yaml")                       # soft failure: nothing is re-created
+    assert np.array_equal(p.get_color_calibration_matrix(), m_before)
+    assert p.query_output(40, 56, 1, "mono8")[:2] == (48, 64)
+    p.load_params(os.path.join(CFG, "params_full.yaml"))
+    assert np.array_equal(p.get_color_calibration_matrix(), np.eye(3))
+    assert p.is_undistortion_enabled() and p.query_output(40, 56, 3, "bgr8")[:2] == (40, 56)    # no calibration any more
