@@ -44,26 +44,19 @@ def main():
 
     proc = RawImagePipeline(False, param_file, calib_file, color_calib_file, device=args.device)
 
-    print("Original parameters:")
-    print("  dist_image_height:", proc.get_dist_image_height())
-    print("  dist_image_width:", proc.get_dist_image_width())
-    print("  dist_distortion_model:", proc.get_dist_distortion_model())
-    print("  dist_camera_matrix:", proc.get_dist_camera_matrix())
-    print("  dist_distortion_coefficients:", proc.get_dist_distortion_coefficients())
-    print("  dist_rectification_matrix:", proc.get_dist_rectification_matrix())
-    print("  dist_projection_matrix:", proc.get_dist_projection_matrix())
-    print("\nNew parameters:")
-    print("  rect_image_height:", proc.get_rect_image_height())
-    print("  rect_image_width:", proc.get_rect_image_width())
-    print("  rect_distortion_model:", proc.get_rect_distortion_model())
-    print("  rect_camera_matrix:", proc.get_rect_camera_matrix())
-    print("  rect_distortion_coefficients:", proc.get_rect_distortion_coefficients())
-    print("  rect_rectification_matrix:", proc.get_rect_rectification_matrix())
-    print("  rect_projection_matrix:", proc.get_rect_projection_matrix())
+    # camera-info getters of both geometries (what the ROS node copies into sensor_msgs/CameraInfo)
+    fields = ("image_height", "image_width", "distortion_model", "camera_matrix", "distortion_coefficients", "rectification_matrix",
+              "projection_matrix")
+    for title, side in (("distorted input (dist)", "dist"), ("after undistortion (rect)", "rect")):
+        print("%s:" % title)
+        for name in fields:
+            value = getattr(proc, "get_%s_%s" % (side, name))()
+            print("  %-28s %s" % (side + "_" + name, np.array2string(np.asarray(value), precision=4, suppress_small=True)
+                                   if not isinstance(value, (str, int)) else value))
 
-    img2 = proc.process(img, "bgr8")   # apply pipeline without modifying input
+    img2 = proc.process(img, "bgr8")   # returns a new image, `img` stays as it was
     before = img.copy()
-    out = proc.apply(img, "bgr8")      # apply pipeline changing the input
+    out = proc.apply(img, "bgr8")      # in place: `img` now holds the result
     assert np.array_equal(out, img2) and np.array_equal(img, out) and not np.array_equal(before, img)
     try:
         from PIL import Image

@@ -10,6 +10,15 @@
 using raw_image_pipeline::Mat;
 using raw_image_pipeline::RawImagePipeline;
 
+// cv::Mat(rows, cols, type) with OpenCV headers, the stand-in's (rows, cols, channels) without
+#ifdef RIP_HAVE_OPENCV
+static Mat make_u8(int rows, int cols, int channels) { return Mat(rows, cols, CV_8UC(channels)); }
+typedef cv::Exception AssertType;
+#else
+static Mat make_u8(int rows, int cols, int channels) { return Mat(rows, cols, channels); }
+typedef raw_image_pipeline::AssertionError AssertType;
+#endif
+
 static int fail(const char* what) {
   std::printf("FAIL: %s\n", what);
   return 1;
@@ -50,7 +59,7 @@ int main(int argc, char** argv) {
   }
   if (mode == "host") {
     try {
-      Mat img(8, 8, 1);
+      Mat img = make_u8(8, 8, 1);
       std::string enc = "bayer_rggb8";
       proc.apply(img, enc);
       return fail("frame processed without a device");
@@ -61,7 +70,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
-  Mat bayer(h, w, 1);
+  Mat bayer = make_u8(h, w, 1);
   unsigned s = 12345u;
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++) {
@@ -78,6 +87,14 @@ int main(int argc, char** argv) {
   Mat tap = proc.getDistDebayeredImage(), col = proc.getDistColorImage(), fin = proc.getProcessedImage();
   if (tap.rows != h || col.rows != h || fin.rows != h || !proc.getRectMask().empty()) return fail("taps");
   if (std::memcmp(fin.data, out.data, (size_t)w * h * 3) != 0) return fail("processed tap");
+  try {  // cvtColor(BGR2Lab) on one channel: cv::Exception with OpenCV, AssertionError without
+    Mat mono = make_u8(h, w, 1);
+    std::memset(mono.data, 7, (size_t)w * h);
+    std::string em = "mono8";
+    proc.process(mono, em);
+    return fail("vignetting on mono8 accepted");
+  } catch (const AssertType&) {
+  }
   try {
     std::string e16 = "bayer_rggb16";
     proc.process(bayer, e16);

@@ -10,10 +10,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "facade_test.cpp")
 
 
-def build_facade_test(tmp_path, rip_lib):
-    exe = str(tmp_path / "facade_test")
+# "stand-in": the facade's own raw_image_pipeline::Mat (-DRIP_NO_OPENCV); "cv": the cv::Mat branch a ROS / pybind11 workspace
+# takes, compiled against tests/cpp/fake_opencv (OpenCV itself is not installable here)
+BRANCHES = {"stand-in": ["-DRIP_NO_OPENCV"], "cv": ["-I", os.path.join(ROOT, "tests", "cpp", "fake_opencv")]}
+
+
+def build_facade_test(tmp_path, rip_lib, branch="stand-in"):
+    exe = str(tmp_path / ("facade_test_" + branch.replace("-", "_")))
     libdir = os.path.join(ROOT, "raw_image_pipeline_amd")
-    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-DRIP_NO_OPENCV", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror"] + BRANCHES[branch] + ["-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
            "-L", libdir, "-l:librip_hip.so", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -28,17 +33,19 @@ def run_env(device):
     return env
 
 
-def test_facade_compiles_and_handles_parameters(tmp_path, rip_lib):
-    exe = build_facade_test(tmp_path, rip_lib)
+@pytest.mark.parametrize("branch", sorted(BRANCHES))
+def test_facade_compiles_and_handles_parameters(tmp_path, rip_lib, branch):
+    exe = build_facade_test(tmp_path, rip_lib, branch)
     r = subprocess.run([exe, "host"], capture_output=True, text=True, env=run_env(-1))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "facade host OK" in r.stdout and "no CPU execution path" in r.stdout
 
 
 @pytest.mark.gpu
-def test_facade_apply_matches_oracle(tmp_path, rip_lib, oracle):
+@pytest.mark.parametrize("branch", sorted(BRANCHES))
+def test_facade_apply_matches_oracle(tmp_path, rip_lib, oracle, branch):
     from helpers import cfg, oracle_run
-    exe = build_facade_test(tmp_path, rip_lib)
+    exe = build_facade_test(tmp_path, rip_lib, branch)
     w, h = 64, 48
     out_path = str(tmp_path / "out.bin")
     r = subprocess.run([exe, "gpu", str(w), str(h), out_path], capture_output=True, text=True, env=run_env(0))

@@ -54,3 +54,28 @@ def test_gpu_matches_golden_ccc_sequence(gpu_pipe, vectors):
     gpu_pipe.reset_white_balance_temporal_consistency()
     for i, frame in enumerate(vectors["in__ccc_sequence"]):
         assert_images_equal(gpu_pipe.process(frame, "bayer_rggb8"), vectors["out__ccc_sequence"][i], "ccc frame %d" % i)
+
+
+OPENCV_VECTORS = os.path.join(HERE, "golden", "opencv_vectors.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(OPENCV_VECTORS), reason="tests/golden/opencv_vectors.npz has not been generated yet: "
+                    "run tools/compare_with_opencv.py --write on a machine with OpenCV (parity of oracle/ vs OpenCV is unpinned until then)")
+def test_opencv_vectors(oracle):
+    """Outputs of a real OpenCV, frozen by tools/compare_with_opencv.py together with the oracle call that must
+    reproduce each of them (function name + arguments): the pin of oracle/ to the reference's arithmetic library."""
+    v = np.load(OPENCV_VECTORS)
+    records = sorted(k[:-3] for k in v.files if k.endswith("_fn"))
+    assert records, "no replayable record in opencv_vectors.npz"
+    for rec in records:
+        fn = getattr(oracle, str(v[rec + "_fn"]))
+        args, k = [], 0
+        while rec + "_arg%d" % k in v.files:
+            a = v[rec + "_arg%d" % k]
+            args.append(a.item() if a.ndim == 0 else a)
+            k += 1
+        got = np.asarray(fn(*args))
+        ref = v[rec]
+        assert got.shape == ref.shape, rec
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16)).max()
+        assert d <= int(v[rec + "_bar"]), "%s (%s): max |oracle - OpenCV %s| = %d" % (rec, v[rec + "_where"], v["opencv_version"], d)
