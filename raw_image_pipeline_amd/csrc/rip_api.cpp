@@ -506,8 +506,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     p->d_work.reserve((size_t)n * 65536 * 2 * sizeof(float));
     p->d_rowbest.reserve((size_t)n * 256 * 2 * sizeof(float));
     p->d_argmax.reserve((size_t)n * 2 * sizeof(int));
-    HIP_CHECK(hipMemsetAsync(p->d_hist.ptr, 0, (size_t)n * 65536 * sizeof(unsigned), p->stream));
-    rip::CccParams cp = {};
+    rip::CccParams cp = {};  // the launcher zeroes the histogram when its kernel accumulates in HBM
     cp.src = d_in;
     cp.src_step = in_step;
     cp.src_frame_stride = in_frame_stride;

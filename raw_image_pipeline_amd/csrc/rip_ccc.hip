@@ -70,59 +70,131 @@ __device__ __forceinline__ void fetch_block2x2(const SrcView& s, int angle, int 
   fetch_flipped(s, angle, y1, x1, out[3][0], out[3][1], out[3][2]);
 }
 
-// Samples per frame: 360 x 270 (small_size_, convolutional_color_constancy.cpp:22).  kHistBlocks workgroups per frame
-// walk them with the resize geometry and the log table in LDS (ten table reads per sample otherwise go to L2).
+// Samples per frame: 360 x 270 (small_size_, convolutional_color_constancy.cpp:22).  The resize geometry and the log
+// table live in LDS (ten table reads per sample otherwise go to L2).
+struct CccSampleTabs {
+  int xofs[360], yofs[540];
+  short ialpha[720], ibeta[540];
+  float logt[256];
+  template <int NT>
+  __device__ __forceinline__ void load(const CccParams& p) {
+    for (int i = threadIdx.x; i < 360; i += NT) xofs[i] = p.geom.xofs[i];
+    for (int i = threadIdx.x; i < 540; i += NT) {
+      yofs[i] = p.geom.yofs[i];
+      ibeta[i] = p.geom.ibeta[i];
+    }
+    for (int i = threadIdx.x; i < 720; i += NT) ialpha[i] = p.geom.ialpha[i];
+    for (int i = threadIdx.x; i < 256; i += NT) logt[i] = p.tabs->log_tab[i];
+  }
+};
+
+// Sample i of the 360 x 270 grid: cv::resize tap arithmetic, grey mask, log-chroma bin.  Returns the bin index
+// u * 256 + v (hist.at(u, v), :260), or -1 when the sample is masked out (calculateHistogramFeature :210-271).
+__device__ __forceinline__ int ccc_sample_bin(const CccParams& p, const CccSampleTabs& tb, const SrcView& s, int i) {
+  const int dy = i / 360, dx = i - dy * 360;
+  int sm[3];
+  int t[4][3];  // taps (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+  if (p.geom.area_fast) {
+    fetch_block2x2(s, p.flip_angle, 2 * dy, 2 * dx, 2 * dy + 1, 2 * dx + 1, t);
+#pragma unroll
+    for (int c = 0; c < 3; c++) sm[c] = (t[0][c] + t[1][c] + t[2][c] + t[3][c] + 2) >> 2;
+  } else {
+    // cv::resize INTER_LINEAR, 8U: Q11 coefficients, two-pass integer arithmetic
+    const int sx = tb.xofs[dx];
+    const int sx1 = sx + 1 < p.dcols ? sx + 1 : sx;
+    const int a0 = tb.ialpha[dx * 2], a1 = tb.ialpha[dx * 2 + 1];
+    const int y0 = tb.yofs[dy * 2], y1 = tb.yofs[dy * 2 + 1];
+    const int b0 = tb.ibeta[dy * 2], b1 = tb.ibeta[dy * 2 + 1];
+    fetch_block2x2(s, p.flip_angle, y0, sx, y1, sx1, t);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      int r0 = t[0][c] * a0 + t[1][c] * a1;
+      int r1 = t[2][c] * a0 + t[3][c] * a1;
+      sm[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    }
+  }
+  float fb = (float)sm[0], fg = (float)sm[1], fr = (float)sm[2];
+  float gray = fb * 0.114f + fg * 0.587f + fr * 0.299f;
+  bool ok = !(gray > p.upper) && (gray > p.lower);
+  if (sm[0] == 0 || sm[1] == 0 || sm[2] == 0) ok = false;  // log(0) = -inf is skipped
+  if (!ok) return -1;
+  const float bin_size = 1.0f / 64.0f, uv0 = -1.421875f;
+  float lb = tb.logt[sm[0]], lg = tb.logt[sm[1]], lr = tb.logt[sm[2]];
+  int u = (int)roundf((lg - lr - uv0) / bin_size);
+  int v = (int)roundf((lg - lb - uv0) / bin_size);
+  u = clampi(u, 0, 255);
+  v = clampi(v, 0, 255);
+  return u * 256 + v;
+}
+
+// Small batches: kHistBlocks workgroups per frame, one global atomic per sample into a zeroed histogram (a frame's
+// samples spread over the chip: lowest latency for a single frame).
 constexpr int kHistBlocks = 24;
 __global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
-  __shared__ int s_xofs[360], s_yofs[540];
-  __shared__ short s_ialpha[720], s_ibeta[540];
-  __shared__ float s_log[256];
-  for (int i = threadIdx.x; i < 360; i += kBlock) s_xofs[i] = p.geom.xofs[i];
-  for (int i = threadIdx.x; i < 540; i += kBlock) {
-    s_yofs[i] = p.geom.yofs[i];
-    s_ibeta[i] = p.geom.ibeta[i];
-  }
-  for (int i = threadIdx.x; i < 720; i += kBlock) s_ialpha[i] = p.geom.ialpha[i];
-  s_log[threadIdx.x] = p.tabs->log_tab[threadIdx.x];
+  __shared__ CccSampleTabs tb;
+  tb.load<kBlock>(p);
   __syncthreads();
   const int frame = blockIdx.y;
   SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < 360 * 270; i += kHistBlocks * kBlock) {
-    const int dy = i / 360, dx = i - dy * 360;
-    int sm[3];
-    int t[4][3];  // taps (y0,x0) (y0,x1) (y1,x0) (y1,x1)
-    if (p.geom.area_fast) {
-      fetch_block2x2(s, p.flip_angle, 2 * dy, 2 * dx, 2 * dy + 1, 2 * dx + 1, t);
+    const int bin = ccc_sample_bin(p, tb, s, i);
+    if (bin >= 0) atomicAdd(&p.hist_counts[(size_t)frame * 65536 + bin], 1u);
+  }
+}
+
+// Batches: no global atomics and no memset.  ONE 1024-thread workgroup per frame holds the whole 256 x 256 histogram in
+// LDS as 16-bit counters, two bins per dword (128 KB), walks the frame's 97 200 samples once with LDS atomics and then
+// writes every bin -- zeros included -- to HBM as u32 with coalesced stores.  A 16-bit counter can wrap: a bin that
+// receives more than 65 535 of the 97 200 samples (a flat frame).  At most one bin per frame can do that, and only once;
+// the returning atomic shows the wrap (old half == 0xFFFF), the carry into the neighbouring bin is taken back and the
+// bin is remembered, so the written count is exact.  Counts are integers: the result does not depend on the order.
+constexpr int kHistLdsThreads = 1024, kHistWords = 32768;
+__global__ __launch_bounds__(kHistLdsThreads) void ccc_hist_lds_kernel(CccParams p) {
+  extern __shared__ __align__(16) unsigned char ccc_smem[];
+  unsigned* words = reinterpret_cast<unsigned*>(ccc_smem);
+  CccSampleTabs& tb = *reinterpret_cast<CccSampleTabs*>(ccc_smem + kHistWords * sizeof(unsigned));
+  __shared__ int wrapped_bin;
+  tb.load<kHistLdsThreads>(p);
+  uint4* z = reinterpret_cast<uint4*>(words);
+  for (int i = threadIdx.x; i < kHistWords / 4; i += kHistLdsThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (threadIdx.x == 0) wrapped_bin = -1;
+  __syncthreads();
+  const int frame = blockIdx.x;
+  SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
+  // two independent samples per thread and trip: their tap loads are in flight together
+  constexpr int kUnroll = 2;
+  for (int i0 = threadIdx.x; i0 < 360 * 270; i0 += kUnroll * kHistLdsThreads) {
+    int bin[kUnroll];
 #pragma unroll
-      for (int c = 0; c < 3; c++) sm[c] = (t[0][c] + t[1][c] + t[2][c] + t[3][c] + 2) >> 2;
-    } else {
-      // cv::resize INTER_LINEAR, 8U: Q11 coefficients, two-pass integer arithmetic
-      const int sx = s_xofs[dx];
-      const int sx1 = sx + 1 < p.dcols ? sx + 1 : sx;
-      const int a0 = s_ialpha[dx * 2], a1 = s_ialpha[dx * 2 + 1];
-      const int y0 = s_yofs[dy * 2], y1 = s_yofs[dy * 2 + 1];
-      const int b0 = s_ibeta[dy * 2], b1 = s_ibeta[dy * 2 + 1];
-      fetch_block2x2(s, p.flip_angle, y0, sx, y1, sx1, t);
+    for (int k = 0; k < kUnroll; k++) {
+      const int i = i0 + k * kHistLdsThreads;
+      bin[k] = i < 360 * 270 ? ccc_sample_bin(p, tb, s, i) : -1;
+    }
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        int r0 = t[0][c] * a0 + t[1][c] * a1;
-        int r1 = t[2][c] * a0 + t[3][c] * a1;
-        sm[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    for (int k = 0; k < kUnroll; k++) {
+      if (bin[k] < 0) continue;
+      const unsigned hi = (unsigned)bin[k] & 1u;
+      const unsigned old = atomicAdd(&words[bin[k] >> 1], hi ? 0x10000u : 1u);
+      if (((old >> (16 * hi)) & 0xFFFFu) == 0xFFFFu) {  // this add wrapped the counter
+        if (!hi) atomicSub(&words[bin[k] >> 1], 0x10000u);  // the carry went into the odd neighbour: take it back
+        wrapped_bin = bin[k];
       }
     }
-    // calculateHistogramFeature (:210-271)
-    float fb = (float)sm[0], fg = (float)sm[1], fr = (float)sm[2];
-    float gray = fb * 0.114f + fg * 0.587f + fr * 0.299f;
-    bool ok = !(gray > p.upper) && (gray > p.lower);
-    if (sm[0] == 0 || sm[1] == 0 || sm[2] == 0) ok = false;  // log(0) = -inf is skipped
-    if (!ok) continue;
-    const float bin_size = 1.0f / 64.0f, uv0 = -1.421875f;
-    float lb = s_log[sm[0]], lg = s_log[sm[1]], lr = s_log[sm[2]];
-    int u = (int)roundf((lg - lr - uv0) / bin_size);
-    int v = (int)roundf((lg - lb - uv0) / bin_size);
-    u = clampi(u, 0, 255);
-    v = clampi(v, 0, 255);
-    atomicAdd(&p.hist_counts[(size_t)frame * 65536 + u * 256 + v], 1u);
+  }
+  __syncthreads();
+  const int wb = wrapped_bin;
+  uint4* out = reinterpret_cast<uint4*>(p.hist_counts + (size_t)frame * 65536);
+  for (int i = threadIdx.x; i < kHistWords / 2; i += kHistLdsThreads) {  // two words = four bins per store
+    const unsigned w0 = words[2 * i], w1 = words[2 * i + 1];
+    uint4 o = make_uint4(w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16);
+    if ((wb >> 2) == i) {
+      const int k = wb & 3;
+      if (k == 0) o.x += 65536u;
+      if (k == 1) o.y += 65536u;
+      if (k == 2) o.z += 65536u;
+      if (k == 3) o.w += 65536u;
+    }
+    out[i] = o;
   }
 }
 
@@ -147,24 +219,6 @@ __device__ __forceinline__ void fft256_lds(float* re, float* im, const float* tw
     im[hi] = ui - ti;
     __syncthreads();
   }
-}
-
-// forward FFT of the histogram rows (counts -> float via the sequential-accumulation table)
-__global__ __launch_bounds__(128) void ccc_fft_rows_kernel(CccParams p) {
-  __shared__ float re[256], im[256], twr[128], twi[128];
-  const int row = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
-  twr[t] = p.tabs->tw_re[t];
-  twi[t] = p.tabs->tw_im[t];
-  const unsigned int* h = p.hist_counts + (size_t)frame * 65536 + row * 256;
-  for (int i = t; i < 256; i += 128) {
-    unsigned j = bitrev8((unsigned)i);
-    re[j] = p.accum_tab[h[i]];
-    im[j] = 0.f;
-  }
-  __syncthreads();
-  fft256_lds(re, im, twr, twi, false);
-  float2* out = reinterpret_cast<float2*>(p.work) + (size_t)frame * 65536 + row * 256;
-  for (int i = t; i < 256; i += 128) out[i] = make_float2(re[i], im[i]);
 }
 
 // Forward FFT of the columns, spectrum product + bias, inverse FFT of the columns.  A workgroup takes
@@ -208,6 +262,74 @@ __device__ __forceinline__ void fft256_columns_lds(float* re, float* im, const f
       cim[hi] = ni[m][1];
     }
     __syncthreads();
+  }
+}
+
+// Row transforms, kFftCols rows per 256-thread workgroup on the same slab code (a row is 1 KB of contiguous floats, so
+// the loads and stores are whole lines as well).  One row per 128-thread workgroup (eight barriers per transform, two waves)
+// was latency-bound: 0.20 ms of the estimator's 0.77 ms per 256 frames.
+__global__ __launch_bounds__(256) void ccc_fft_rows16_kernel(CccParams p) {
+  __shared__ float re[kFftCols * kFftPitch], im[kFftCols * kFftPitch], twr[128], twi[128];
+  const int row0 = blockIdx.x * kFftCols, frame = blockIdx.y, t = threadIdx.x;
+  if (t < 128) {
+    twr[t] = p.tabs->tw_re[t];
+    twi[t] = p.tabs->tw_im[t];
+  }
+  const unsigned int* h = p.hist_counts + (size_t)frame * 65536 + (size_t)row0 * 256;
+  for (int e = t; e < kFftCols * 256; e += 256) {  // e = r * 256 + i: consecutive lanes read consecutive counters
+    const int r = e >> 8, i = e & 255;
+    re[r * kFftPitch + bitrev8((unsigned)i)] = p.accum_tab[h[e]];
+    im[r * kFftPitch + bitrev8((unsigned)i)] = 0.f;
+  }
+  __syncthreads();
+  fft256_columns_lds(re, im, twr, twi, false);
+  float2* out = reinterpret_cast<float2*>(p.work) + (size_t)frame * 65536 + (size_t)row0 * 256;
+  for (int e = t; e < kFftCols * 256; e += 256) {
+    const int r = e >> 8, i = e & 255;
+    out[e] = make_float2(re[r * kFftPitch + i], im[r * kFftPitch + i]);
+  }
+}
+
+// inverse FFT of kFftCols rows; per-row first maximum of the real part
+__global__ __launch_bounds__(256) void ccc_ifft_rows16_kernel(CccParams p) {
+  __shared__ float re[kFftCols * kFftPitch], im[kFftCols * kFftPitch], twr[128], twi[128];
+  const int row0 = blockIdx.x * kFftCols, frame = blockIdx.y, t = threadIdx.x;
+  if (t < 128) {
+    twr[t] = p.tabs->tw_re[t];
+    twi[t] = p.tabs->tw_im[t];
+  }
+  const float2* in = reinterpret_cast<const float2*>(p.work) + (size_t)frame * 65536 + (size_t)row0 * 256;
+  for (int e = t; e < kFftCols * 256; e += 256) {
+    const int r = e >> 8, i = e & 255;
+    const float2 v = in[e];
+    re[r * kFftPitch + bitrev8((unsigned)i)] = v.x;
+    im[r * kFftPitch + bitrev8((unsigned)i)] = v.y;
+  }
+  __syncthreads();
+  fft256_columns_lds(re, im, twr, twi, true);
+  // first maximum of each row: 16 lanes per row, each scans 16 consecutive columns in order, then a 16-lane min-index
+  // reduction with the same tie rule (larger value, else smaller column)
+  const int r = t >> 4, l = t & 15;
+  float bv = re[r * kFftPitch + l * 16];
+  int bi = l * 16;
+  for (int k = 1; k < 16; k++) {
+    const float v = re[r * kFftPitch + l * 16 + k];
+    if (v > bv) {
+      bv = v;
+      bi = l * 16 + k;
+    }
+  }
+  for (int off = 8; off > 0; off >>= 1) {
+    const float ov = __shfl_down(bv, off, 16);
+    const int oi = __shfl_down(bi, off, 16);
+    if (ov > bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  if (l == 0) {
+    p.row_best[((size_t)frame * 256 + row0 + r) * 2] = bv;
+    p.row_best[((size_t)frame * 256 + row0 + r) * 2 + 1] = (float)bi;
   }
 }
 
@@ -255,44 +377,6 @@ __global__ __launch_bounds__(256) void ccc_fft_cols_kernel(CccParams p) {
   for (int i = r0; i < 256; i += 16) data[(size_t)i * 256] = make_float2(re[c * kFftPitch + i], im[c * kFftPitch + i]);
 }
 
-// inverse FFT of the rows; per-row first maximum of the real part
-__global__ __launch_bounds__(128) void ccc_ifft_rows_kernel(CccParams p) {
-  __shared__ float re[256], im[256], twr[128], twi[128];
-  __shared__ float bv[128];
-  __shared__ int bi[128];
-  const int row = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
-  twr[t] = p.tabs->tw_re[t];
-  twi[t] = p.tabs->tw_im[t];
-  const float2* in = reinterpret_cast<const float2*>(p.work) + (size_t)frame * 65536 + row * 256;
-  for (int i = t; i < 256; i += 128) {
-    float2 v = in[i];
-    unsigned j = bitrev8((unsigned)i);
-    re[j] = v.x;
-    im[j] = v.y;
-  }
-  __syncthreads();
-  fft256_lds(re, im, twr, twi, true);
-  float v0 = re[t], v1 = re[t + 128];
-  bv[t] = v1 > v0 ? v1 : v0;
-  bi[t] = v1 > v0 ? t + 128 : t;
-  __syncthreads();
-  for (int off = 64; off > 0; off >>= 1) {
-    if (t < off) {
-      float ov = bv[t + off];
-      int oi = bi[t + off];
-      if (ov > bv[t] || (ov == bv[t] && oi < bi[t])) {
-        bv[t] = ov;
-        bi[t] = oi;
-      }
-    }
-    __syncthreads();
-  }
-  if (t == 0) {
-    p.row_best[((size_t)frame * 256 + row) * 2] = bv[0];
-    p.row_best[((size_t)frame * 256 + row) * 2 + 1] = (float)bi[0];
-  }
-}
-
 // cv::minMaxLoc: first maximum in row-major order -> Point(x = column, y = row)
 __global__ __launch_bounds__(256) void ccc_argmax_kernel(CccParams p) {
   __shared__ float bv[256];
@@ -323,10 +407,21 @@ __global__ __launch_bounds__(256) void ccc_argmax_kernel(CccParams p) {
 
 void launch_ccc_estimate(const CccParams& p, hipStream_t stream) {
   if (p.n_frames <= 0) return;
-  hipLaunchKernelGGL(ccc_hist_kernel, dim3(kHistBlocks, p.n_frames), dim3(kBlock), 0, stream, p);
-  hipLaunchKernelGGL(ccc_fft_rows_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
+  // RIP_CCC_LDS_HIST_MIN: smallest batch that takes the LDS histogram (one workgroup = one CU per frame)
+  const int lds_min = tune_int("RIP_CCC_LDS_HIST_MIN", 48);
+  if (p.n_frames >= lds_min) {
+    constexpr unsigned lds = kHistWords * sizeof(unsigned) + sizeof(CccSampleTabs);
+    static const bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(ccc_hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)lds) == hipSuccess);
+    (void)attr;
+    hipLaunchKernelGGL(ccc_hist_lds_kernel, dim3(p.n_frames), dim3(kHistLdsThreads), lds, stream, p);
+  } else {
+    (void)hipMemsetAsync(p.hist_counts, 0, (size_t)p.n_frames * 65536 * sizeof(unsigned), stream);
+    hipLaunchKernelGGL(ccc_hist_kernel, dim3(kHistBlocks, p.n_frames), dim3(kBlock), 0, stream, p);
+  }
+  hipLaunchKernelGGL(ccc_fft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(ccc_fft_cols_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
-  hipLaunchKernelGGL(ccc_ifft_rows_kernel, dim3(256, p.n_frames), dim3(128), 0, stream, p);
+  hipLaunchKernelGGL(ccc_ifft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(ccc_argmax_kernel, dim3(p.n_frames), dim3(256), 0, stream, p);
 }
 

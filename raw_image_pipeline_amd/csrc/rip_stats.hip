@@ -239,60 +239,83 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
                                    const DevTables* tabs, FrameWb* out, int n_frames, const unsigned* simple_hist,
                                    float simple_p, int simple_total) {
   if (mode == WB_FLOAT) {
-    // ccc: temporal filter is sequential over the frames of the stream
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    CccState s = *st;
-    for (int f = 0; f < n_frames; f++) {
-      s.uv_x = ccc_argmax[2 * f];
-      s.uv_y = ccc_argmax[2 * f + 1];
-      FrameWb w = {};
-      w.uv_raw[0] = s.uv_x;
-      w.uv_raw[1] = s.uv_y;
-      if (s.temporal) {
-        if (s.first_frame) {
-          s.first_frame = 0;
-          s.st_x = (float)s.uv_x;
-          s.st_y = (float)s.uv_y;
-        } else {
-          // cv::KalmanFilter(2,2,0) predict + correct with A = I, Q = I, H = h I, R = r I
-          float xs[2] = {s.st_x, s.st_y}, ps[2] = {s.p_x, s.p_y};
-          int z[2] = {s.uv_x, s.uv_y}, o[2];
-          for (int a = 0; a < 2; a++) {
-            float x_pre = xs[a];
-            float p_pre = ps[a] + 1.0f;
-            float t2 = s.kf_h * p_pre;
-            float t3 = t2 * s.kf_h + s.kf_r;
-            float k = t2 / t3;
-            float innov = (float)z[a] - s.kf_h * x_pre;
-            xs[a] = x_pre + k * innov;
-            ps[a] = p_pre - k * t2;
-            o[a] = (int)xs[a];
-          }
-          s.st_x = xs[0];
-          s.st_y = xs[1];
-          s.p_x = ps[0];
-          s.p_y = ps[1];
-          s.uv_x = o[0];
-          s.uv_y = o[1];
-        }
+    // ccc (one workgroup): the temporal filter is sequential over the frames of the stream -- one lane walks it over
+    // argmax values staged in LDS (a handful of float operations per frame) -- while loading the argmax pairs and turning
+    // the filtered (u, v) into gains and FrameWb records is done by all lanes, a frame each.
+    constexpr int kChunk = 1024;
+    __shared__ int s_raw[kChunk][2], s_flt[kChunk][2];
+    __shared__ CccState s_state;
+    if (threadIdx.x == 0) s_state = *st;
+    for (int f0 = 0; f0 < n_frames; f0 += kChunk) {
+      const int n = min(kChunk, n_frames - f0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        s_raw[i][0] = ccc_argmax[2 * (f0 + i)];
+        s_raw[i][1] = ccc_argmax[2 * (f0 + i) + 1];
       }
-      // computeGains (:342-381) with exp(-L) taken from the host-built table
-      int ux = clampi(s.uv_x, 0, 255), uy = clampi(s.uv_y, 0, 255);
-      float gain_r = 1.0f / tabs->exp_neg_tab[ux];
-      float gain_g = 1.0f;
-      float gain_b = 1.0f / tabs->exp_neg_tab[uy];
-      float factor = fminf(fminf(gain_r, gain_g), gain_b);
-      gain_r /= factor;
-      gain_g /= factor;
-      gain_b /= factor;
-      w.fg[0] = gain_b;
-      w.fg[1] = gain_g;
-      w.fg[2] = gain_r;
-      w.uv[0] = s.uv_x;
-      w.uv[1] = s.uv_y;
-      out[f] = w;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        CccState s = s_state;
+        for (int i = 0; i < n; i++) {
+          s.uv_x = s_raw[i][0];
+          s.uv_y = s_raw[i][1];
+          if (s.temporal) {
+            if (s.first_frame) {
+              s.first_frame = 0;
+              s.st_x = (float)s.uv_x;
+              s.st_y = (float)s.uv_y;
+            } else {
+              // cv::KalmanFilter(2,2,0) predict + correct with A = I, Q = I, H = h I, R = r I
+              float xs[2] = {s.st_x, s.st_y}, ps[2] = {s.p_x, s.p_y};
+              int z[2] = {s.uv_x, s.uv_y}, o[2];
+              for (int a = 0; a < 2; a++) {
+                float x_pre = xs[a];
+                float p_pre = ps[a] + 1.0f;
+                float t2 = s.kf_h * p_pre;
+                float t3 = t2 * s.kf_h + s.kf_r;
+                float k = t2 / t3;
+                float innov = (float)z[a] - s.kf_h * x_pre;
+                xs[a] = x_pre + k * innov;
+                ps[a] = p_pre - k * t2;
+                o[a] = (int)xs[a];
+              }
+              s.st_x = xs[0];
+              s.st_y = xs[1];
+              s.p_x = ps[0];
+              s.p_y = ps[1];
+              s.uv_x = o[0];
+              s.uv_y = o[1];
+            }
+          }
+          s_flt[i][0] = s.uv_x;
+          s_flt[i][1] = s.uv_y;
+        }
+        s_state = s;
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        FrameWb w = {};
+        w.uv_raw[0] = s_raw[i][0];
+        w.uv_raw[1] = s_raw[i][1];
+        // computeGains (:342-381) with exp(-L) taken from the host-built table
+        const int ux = clampi(s_flt[i][0], 0, 255), uy = clampi(s_flt[i][1], 0, 255);
+        float gain_r = 1.0f / tabs->exp_neg_tab[ux];
+        float gain_g = 1.0f;
+        float gain_b = 1.0f / tabs->exp_neg_tab[uy];
+        float factor = fminf(fminf(gain_r, gain_g), gain_b);
+        gain_r /= factor;
+        gain_g /= factor;
+        gain_b /= factor;
+        w.fg[0] = gain_b;
+        w.fg[1] = gain_g;
+        w.fg[2] = gain_r;
+        w.uv[0] = s_flt[i][0];
+        w.uv[1] = s_flt[i][1];
+        out[f0 + i] = w;
+      }
     }
-    *st = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *st = s_state;
     return;
   }
   int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -426,7 +449,7 @@ void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax
                         float simple_p, int simple_total) {
   if (n_frames <= 0) return;
   if (mode == WB_FLOAT) {
-    hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(64), 0, stream, mode, stats, ccc_argmax, ccc_state, tabs, out, n_frames,
+    hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(256), 0, stream, mode, stats, ccc_argmax, ccc_state, tabs, out, n_frames,
                        simple_hist, simple_p, simple_total);
   } else {
     hipLaunchKernelGGL(wb_finalize_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, mode, stats, ccc_argmax,

@@ -392,6 +392,42 @@ def test_config3_full_size_1920x1200_ccc_batch(gpu_pipe, oracle):
         assert_images_equal(out[i], ref, "config3 frame %d" % i, TOL_DECLARED)
 
 
+@pytest.mark.parametrize("size,pattern,flip", [((384, 240), "bayer_gbrg8", 0), ((720, 540), "bayer_rggb8", 180), ((250, 190), "bayer_bggr8", 90)])
+def test_ccc_lds_histogram_path(gpu_pipe, oracle, monkeypatch, size, pattern, flip):
+    """Batches take the estimator whose histogram is accumulated in LDS (two workgroups per frame, no global atomics, no
+    memset, 16-bit counters with wrap repair); small batches the atomic one.  Forced on here for a short batch: every frame equals the oracle, and equals
+    what the atomic path gives (bilinear and exact-2x area resize, flipped sampling, generic geometry)."""
+    import torch
+    w, h = size
+    n = 5
+    filt, bias = synth.ccc_model()
+    gpu_pipe.set_ccc_model(filt, bias)
+    gpu_pipe.set_ccc_kalman_model(1.0, 10.0)
+    # temporal consistency off: the filter's covariance survives resetWhiteBalanceTemporalConsistency, so two passes over the
+    # same frames would legitimately differ; the estimator itself (histogram -> argmax -> gains) is what is compared
+    c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=False, flip=flip != 0, flip_angle=flip)
+    configure(gpu_pipe, c)
+    frames = np.stack([synth.gen_frame(w, h, pattern, seed=7000 + i, kind="scene", tint=(0.62 + 0.05 * i, 1.0, 0.5)) for i in range(n)])
+    # last frame: a flat colour, so that (nearly) all 97 200 samples land in ONE bin and its 16-bit LDS counter wraps
+    flat = np.empty((h, w), np.uint8)
+    for i in range(2):
+        for j in range(2):
+            flat[i::2, j::2] = (90, 200, 120)[synth.PATTERNS[pattern][i][j]]  # B, G, R
+    frames[-1] = flat
+    dev = torch.from_numpy(frames).cuda()
+    outs = {}
+    for mode, lds_min in (("lds", "1"), ("atomic", "1000000")):
+        monkeypatch.setenv("RIP_CCC_LDS_HIST_MIN", lds_min)
+        outs[mode] = gpu_pipe.apply_device(dev, pattern).cpu().numpy()
+        outs[mode + "_uv"] = gpu_pipe.get_white_balance_info(n)[:, 6:8].copy()
+    assert np.array_equal(outs["lds"], outs["atomic"]) and np.array_equal(outs["lds_uv"], outs["atomic_uv"])
+    assert len({tuple(uv) for uv in outs["lds_uv"]}) > 1, "the drifting tint must move the estimate"
+    occ = oracle.CCC(filt, bias)
+    for i in range(n):
+        ref, _ = oracle_run(oracle, c, frames[i], pattern, ccc=occ)
+        assert_images_equal(outs["lds"][i], ref, "ccc lds histogram frame %d" % i, TOL_DECLARED)
+
+
 def test_config5_full_size_3840x2160_debayer_undistort(gpu_pipe, oracle):
     """BASELINE configs[4] at its own size: 3840x2160 rggb8, debayer + fisheye undistortion."""
     w, h = 3840, 2160
