@@ -112,7 +112,7 @@ constexpr int fast_waves_per_simd() {
 // The per-pixel stages after the demosaic for the four pixels of one row.
 template <int BITS, int WB>
 __device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const VigRegs& vr,
-                                           const CcRegs& cc, const float (&mask)[4], int (&q)[4][3]) {
+                                           const CcRegs& cc, const HsvRegs& hr, const float (&mask)[4], int (&q)[4][3]) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     apply_wb(WB, w, q[k][0], q[k][1], q[k][2]);
@@ -128,7 +128,7 @@ __device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& 
   }
   if constexpr ((BITS & ST_HSV) != 0) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) apply_hsv(p, tb, q[k][0], q[k][1], q[k][2]);
+    for (int k = 0; k < 4; k++) apply_hsv(hr.g, tb, q[k][0], q[k][1], q[k][2]);
   }
 }
 
@@ -140,6 +140,8 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
   if constexpr ((BITS & ST_VIG) != 0) vr.load();
   CcRegs cc = {};
   if constexpr ((BITS & ST_CC) != 0) cc.load(p);
+  HsvRegs hr = {};
+  if constexpr ((BITS & ST_HSV) != 0) hr.load(p);
   __syncthreads();
   // Persistent workgroups: the LDS tables are loaded once and amortised over many chunks of
   // NT items.  Block b runs on XCD b % 8 (observed dispatch order; speed only), so each
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
           q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
           q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
         }
-        pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, vr, cc, mask[ly], q);
+        pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, vr, cc, hr, mask[ly], q);
 #ifdef RIP_EXP_EXTRA  // experiment: extra independent full-rate VALU work per row (is the kernel VALU-issue bound?)
         {
           unsigned dummy = (unsigned)q[0][0];
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, Item
           g = s_gamma[g];
           r = s_gamma[r];
         }
-        if (p.stage_bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+        if (p.stage_bits & ST_HSV) apply_hsv(p.hsv_gain, tb, b, g, r);
         q[k][0] = b;
         q[k][1] = g;
         q[k][2] = r;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int ti
             g = s_gamma[g];
             r = s_gamma[r];
           }
-          if (p.stage_bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+          if (p.stage_bits & ST_HSV) apply_hsv(p.hsv_gain, tb, b, g, r);
           pix[ly][k] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
         }
       const int first = rot90 ? 1 : 0;  // which source row lands in the left destination column
@@ -494,7 +496,8 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     const long long chunks = (long long)((items + nt - 1) / nt);
     // persistent grid: at most 256 CUs x 8 x 256 threads, a multiple of 8 workgroups (one share per XCD; the kernel
     // strides its chunk loop by gridDim.x / 8)
-    const int cap = std::max(8, tune_grid("RIP_CHAIN_BLOCKS", 2048) * kBlock / nt / 8 * 8);
+    // (the 512-thread vignetting variants run ~3 % faster with one chunk per workgroup than with a 768-workgroup persistent grid)
+    const int cap = std::max(8, tune_grid("RIP_CHAIN_BLOCKS", nt == kBlock ? 2048 : 4096) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
     dim3 grid(blocks, frame_groups(p, cap, blocks));
     switch (p.stage_bits & 15) {

@@ -238,6 +238,16 @@ struct CcRegs {
     }
   }
 };
+struct HsvRegs {
+  float g[3];  // gains on H, S, V (VGPR copies, same reason)
+  __device__ __forceinline__ void load(const ChainParams& p) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      g[i] = p.hsv_gain[i];
+      asm volatile("" : "+v"(g[i]));
+    }
+  }
+};
 // color_calibration.cpp:93-103: ((m0*B + m1*G) + m2*R) + bias in float32, no FMA
 __device__ __forceinline__ void apply_cc(const ChainParams& p, const CcRegs& cc, int& b, int& g, int& r) {
   float fb = (float)b, fg = (float)g, fr = (float)r;
@@ -509,10 +519,23 @@ __device__ __forceinline__ void vignette4(const VigTabs& tb, const VigRegs& vr, 
   }
 }
 
+// max / min of two floats with the VOP3 output clamp to [0, 1]: one instruction (hipcc turns __saturatef into two compares
+// and two selects)
+__device__ __forceinline__ float max_sat(float a, float b) {
+  float d;
+  asm("v_max_f32_e64 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float min_sat(float a, float b) {
+  float d;
+  asm("v_min_f32_e64 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 // color_enhancer.cpp:38-47: RGB2HSV_b (H in [0,180)), float gain with u8 saturation,
 // HSV2RGB_b (float)
 template <typename Tabs>
-__device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, int& b, int& g, int& r) {
+__device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, int& b, int& g, int& r) {
   int v = max(b, max(g, r)), vmin = min(b, min(g, r));
   int diff = v - vmin;
   int s = (mul24(diff, tb.sdiv(v)) + (1 << 11)) >> 12;
@@ -526,30 +549,27 @@ __device__ __forceinline__ void apply_hsv(const ChainParams& p, const Tabs& tb, 
   h = (mul24(h, tb.hdiv(diff)) + (1 << 11)) >> 12;
   h += h < 0 ? 180 : 0;
   h = clampi(h, 0, 255);
-  int H = sat_round_u8((float)h * p.hsv_gain[0]);
-  int S = sat_round_u8((float)s * p.hsv_gain[1]);
-  int V = sat_round_u8((float)v * p.hsv_gain[2]);
-  float fh = (float)H, fs = (float)S * (1.f / 255.f), fv = (float)V * (1.f / 255.f);
-  // HSV2RGB_f (color_hsv.cpp): tab = {v, v(1-s), v(1-s*f), v(1-s*(1-f))}, (b, g, r) = tab[sector_data[sector][..]].
-  // Branch-free: the per-lane sector would otherwise run up to six divergent case bodies per pixel.  With s == 0
-  // every entry of tab equals v exactly, so OpenCV's early-out needs no branch either.
+  // cv::multiply(hsv, Scalar(gains)): saturate_cast<uchar>(float(x) * gain) per channel, then back to float for HSV2RGB_f
+  const float fH = (float)sat_round_u8((float)h * hg[0]);
+  const float fS = (float)sat_round_u8((float)s * hg[1]);
+  const float fV = (float)sat_round_u8((float)v * hg[2]);
+  float fh = fH, fs = fS * (1.f / 255.f), fv = fV * (1.f / 255.f);
+  // HSV2RGB_f (color_hsv.cpp): tab = {v, v(1-s), v(1-s*f), v(1-s*(1-f))}, (b, g, r) = tab[sector_data[sector][..]], i.e.
+  // every output channel is v * (1 - s * w) with w in {0, 1, f, 1 - f} chosen by the sector (w = 0 and w = 1 reproduce tab[0]
+  // and tab[1] exactly).  As a function of h = sector + f in [0, 6) the three weights are piecewise linear:
+  //   w_b = sat(max(3 - h, h - 5))   w_g = sat(max(1 - h, h - 3))   w_r = sat(min(h - 1, 5 - h))
+  // and each linear piece is bit-identical to OpenCV's f = h - sector or 1.f - f: h - k is exact for the integer k = sector,
+  // and e.g. 5 - h and 1 - (h - 4) are single roundings of the same real number.  No sector, no per-lane select: three
+  // subtract pairs, three min/max with the free [0, 1] output clamp.  With s == 0 every channel is v * 1 = v exactly, which
+  // is OpenCV's early-out.
   fh = fh * (6.f / 180.f);
-  fh = fh >= 6.f ? fh - 6.f : fh;  // fmod(h, 6): h <= 255/30 < 12
-  int sector = (int)fh;            // floor, h >= 0
-  fh = fh - (float)sector;
-  const bool bad = (unsigned)sector >= 6u;
-  sector = bad ? 0 : sector;
-  fh = bad ? 0.f : fh;
-  const float t0 = fv;
-  const float t1 = fv * (1.f - fs);
-  const float t2 = fv * (1.f - fs * fh);
-  const float t3 = fv * (1.f - fs * (1.f - fh));
-  // sector: 0 (t1,t3,t0)  1 (t1,t0,t2)  2 (t3,t0,t1)  3 (t0,t2,t1)  4 (t0,t1,t3)  5 (t2,t1,t0)
-  const float m = (sector & 1) ? t2 : t3;  // the f-dependent entry of this sector
-  const unsigned oh = 1u << sector;
-  const float ob = (oh & 0x24u) ? m : ((oh & 0x03u) ? t1 : t0);
-  const float og = (oh & 0x09u) ? m : ((oh & 0x06u) ? t0 : t1);
-  const float orr = (oh & 0x12u) ? m : ((oh & 0x21u) ? t0 : t1);
+  fh = fh >= 6.f ? fh - 6.f : fh;  // fmod(h, 6): h <= 255/30 < 12, and h >= 0, so sector is always in [0, 5]
+  const float wb = max_sat(3.f - fh, fh - 5.f);
+  const float wg = max_sat(1.f - fh, fh - 3.f);
+  const float wr = min_sat(fh - 1.f, 5.f - fh);
+  const float ob = fv * (1.f - fs * wb);
+  const float og = fv * (1.f - fs * wg);
+  const float orr = fv * (1.f - fs * wr);
   b = sat_round_u8(ob * 255.f);
   g = sat_round_u8(og * 255.f);
   r = sat_round_u8(orr * 255.f);
@@ -570,7 +590,7 @@ __device__ __forceinline__ void pointwise(const ChainParams& p, const FrameWb& w
     g = tb.gamma(g);
     r = tb.gamma(r);
   }
-  if (bits & ST_HSV) apply_hsv(p, tb, b, g, r);
+  if (bits & ST_HSV) apply_hsv(p.hsv_gain, tb, b, g, r);
 }
 
 // ------------------------------------------------------------------------------------------------
