@@ -326,9 +326,15 @@ def main():
             if led:
                 items_per_s = px / 8.0 / 64.0 * args.batch / avg_s  # wave-items per second
                 peak = 1024 * led["clock_GHz"] * 1e9              # SIMD issue cycles per second on 256 CUs
-                roofline["valu"] = {"issue_cycles_per_wave_item": led["valu_cycles_per_item"], "lds_cycles_per_wave_item": led["lds_cycles_per_item"],
-                                    "achieved": round(items_per_s * led["valu_cycles_per_item"] / 1e9, 1), "peak": round(peak / 1e9, 1),
-                                    "unit": "G issue-cycles/s", "frac": round(items_per_s * led["valu_cycles_per_item"] / peak, 4),
+                ach = items_per_s * led["valu_cycles_per_item"]
+                # `frac` above 1 is not possible on the hardware: the per-class issue costs were measured on dependent pairs of
+                # ONE opcode; a mixed stream overlaps better, so the ledger over-prices by 10-35 %.  It is
+                # capped at 1 and the raw ratio kept beside it: the kernel has no VALU issue slack left.
+                roofline["valu"] = {"instr_per_wave_item": led["valu_instr_per_item"], "issue_cycles_per_wave_item": led["valu_cycles_per_item"],
+                                    "lds_cycles_per_wave_item": led["lds_cycles_per_item"], "achieved": round(ach / 1e9, 1),
+                                    "peak": round(peak / 1e9, 1), "unit": "G issue-cycles/s", "frac": round(min(1.0, ach / peak), 4),
+                                    "ledger_over_peak": round(ach / peak, 4),
+                                    "valu_instr_per_simd_cycle": round(items_per_s * led["valu_instr_per_item"] / peak, 4),
                                     "lds_frac": round(items_per_s * led["lds_cycles_per_item"] * 4 / peak, 4), "source": "profiles/chain_ledger.json"}
                 roofline["bound"] = "valu+lds"
         except Exception:

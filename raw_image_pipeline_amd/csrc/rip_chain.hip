@@ -119,7 +119,8 @@ __device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& 
     if constexpr ((BITS & ST_CC) != 0) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
   }
   if constexpr ((BITS & ST_VIG) != 0) {
-    vignette4(tb.vig.v, vr, mask, q);  // gamma folded into VigTabs::lin by the host
+#pragma unroll
+    for (int k0 = 0; k0 < 4; k0 += RIP_VIG_GROUP) vignette_n<RIP_VIG_GROUP>(tb.vig.v, vr, mask + k0, q + k0);  // gamma folded into VigTabs::lin by the host
   } else if constexpr ((BITS & ST_GAMMA) != 0) {
 #pragma unroll
     for (int k = 0; k < 4; k++)

@@ -374,7 +374,8 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
 //    4-lane block holds) was measured too: bit-identical, but 8.4 cycles per MFMA and no overlap with the VALU
 //    issue of the other waves, i.e. slower than the FMAs it replaces (RIP_LAB_MFMA=1 keeps it for A/B runs).
 //  * LabCbrtTab_b re-tabulated as three float tables whose entries already carry the factors and
-//    tie-breaking offsets of the L / a / b formulas: X -> 25 f + 1/8, Y -> {L, 25 f}, Z -> 25 f - 1/8, so
+//    tie-breaking offsets of the L / a / b formulas: X -> 25 f + 1/8, Y -> {L, 25 f}, Z -> 25 f - 1/8 (or the X table
+//    again and + 1/4 after the subtraction: RIP_VIG_SHARED_XZ), so
 //    a = RN((X - Y) * 5 / 8192) + 128 and b = RN((Y - Z) / 4096) + 128 exactly (the +-1/8 turns CV_DESCALE's
 //    round-half-up into a never-tying round-to-nearest; every table index stays <= 2040 because each
 //    forward row sums to 4096).
@@ -391,11 +392,19 @@ constexpr int kLabFwd[9] = {778, 1541, 1777, 296, 2929, 871, 3575, 448, 73};
 constexpr int kLabInv[9] = {217, -836, 4715, -3773, 7684, 185, 12615, -6296, -2223};
 constexpr int kVigCbrtN = 2048;  // LabCbrtTab_b indices reachable from 8-bit input: 0 .. 2040
 constexpr int kZoff = 27500;     // z in [-999, 59828] -> z - kZoff fits int16
+#ifndef RIP_VIG_SHARED_XZ
+#define RIP_VIG_SHARED_XZ 1  // one 25 f + 1/8 table for the X and the Z lookup (the Z side adds 1/4 after the subtraction): 8 KB less LDS
+#endif
+#ifndef RIP_VIG_GROUP
+#define RIP_VIG_GROUP 4      // pixels of a row taken through the round trip together (ILP against live registers)
+#endif
 struct VigTabs {
   float lin[256];
   float cbx[kVigCbrtN];
   float2 cby[kVigCbrtN];
+#if !RIP_VIG_SHARED_XZ
   float cbz[kVigCbrtN];
+#endif
   int4 yf[256];
   uint8_t invg[4096];
   template <int NT>
@@ -420,7 +429,9 @@ struct VigTabs {
       const int L = clampi((296 * f - 1336934 + (1 << 14)) >> 15, 0, 255);
       cbx[i] = f25 + 0.125f;
       cby[i] = make_float2((float)L, f25);
+#if !RIP_VIG_SHARED_XZ
       cbz[i] = f25 - 0.125f;
+#endif
     }
     uint32_t* d = reinterpret_cast<uint32_t*>(invg);
     const uint32_t* s = reinterpret_cast<const uint32_t*>(t->inv_gamma);
@@ -447,12 +458,13 @@ struct VigRegs {
 };
 
 // Four pixels of one row through BGR -> Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93).
-__device__ __forceinline__ void vignette4(const VigTabs& tb, const VigRegs& vr, const float (&mask)[4], int (&q)[4][3]) {
+template <int N>
+__device__ __forceinline__ void vignette_n(const VigTabs& tb, const VigRegs& vr, const float* mask, int (*q)[3]) {
   constexpr float kMagic = 12582912.0f;         // 1.5 * 2^23: ulp 1 in [2^23, 2^24)
   constexpr unsigned kMagicBits = 0x4B400000u;  // its bit pattern
-  unsigned ix[4], iy[4], iz[4];
+  unsigned ix[N], iy[N], iz[N];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < N; k++) {
     const float v0 = tb.lin[q[k][0]], v1 = tb.lin[q[k][1]], v2 = tb.lin[q[k][2]];
     // acc_r = (C_r . v + 0.5) / 4096, exact; RN(acc_r + magic) = (C_r . v + 2048) >> 12 (never a tie)
     f32x4 acc = {1.0f / 8192.0f, 1.0f / 8192.0f, 1.0f / 8192.0f, 0.0f};
@@ -471,16 +483,25 @@ __device__ __forceinline__ void vignette4(const VigTabs& tb, const VigRegs& vr, 
     iy[k] = __float_as_uint(acc[1] + kMagic) - kMagicBits;
     iz[k] = __float_as_uint(acc[2] + kMagic) - kMagicBits;
   }
-  int fx[4], fz[4], x[4], z[4];
-  int4 e[4];
+  int fx[N], fz[N], x[N], z[N];
+  int4 e[N];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < N; k++) {
+#if RIP_VIG_SHARED_XZ
+    const float X = tb.cbx[ix[k]], Zt = tb.cbx[iz[k]];
+#else
     const float X = tb.cbx[ix[k]], Z = tb.cbz[iz[k]];
+#endif
     const float2 LY = tb.cby[iy[k]];
     const int L = sat_round_u8(LY.x * mask[k]);  // convertTo(32F), multiply, convertTo(8U)
     // a, b never leave [0, 255] (exhaustive test), so saturate_cast is dead; abits = kMagicBits + a
     const unsigned abits = __float_as_uint(__builtin_fmaf(X - LY.y, 5.0f / 8192.0f, kMagic + 128.0f));
+#if RIP_VIG_SHARED_XZ
+    // 25 fY - (25 fZ + 1/8) + 1/4 = 25 (fY - fZ) + 1/8, exact (multiples of 1/8 below 2^20)
+    const unsigned bbits = __float_as_uint(__builtin_fmaf((LY.y - Zt) + 0.25f, 1.0f / 4096.0f, kMagic + 128.0f));
+#else
     const unsigned bbits = __float_as_uint(__builtin_fmaf(LY.y - Z, 1.0f / 4096.0f, kMagic + 128.0f));
+#endif
     e[k] = tb.yf[L];
     // adiv = ((5 * a * 53687 + 128) >> 13) - 128 * BASE / 500, bdiv = ((b * 41943 + 16) >> 9) - 128 * BASE / 200 + 1:
     // the 24-bit multiply reads 0x400000 + a; the constant takes 0x400000 * K back and carries the subtrahend
@@ -495,17 +516,19 @@ __device__ __forceinline__ void vignette4(const VigTabs& tb, const VigRegs& vr, 
     x[k] = ab_to_xz_cube(fx[k]);
     z[k] = ab_to_xz_cube(fz[k]);
   }
-  // abToXZ_b's linear segment (i <= 3390: L* below ~8) is rare: one wave-uniform test for the four pixels
-  const int lo = min(min(min(fx[0], fz[0]), min(fx[1], fz[1])), min(min(fx[2], fz[2]), min(fx[3], fz[3])));
+  // abToXZ_b's linear segment (i <= 3390: L* below ~8) is rare: one wave-uniform test for the group
+  int lo = min(fx[0], fz[0]);
+#pragma unroll
+  for (int k = 1; k < N; k++) lo = min(lo, min(fx[k], fz[k]));
   if (__builtin_amdgcn_ballot_w64(lo <= 3390) != 0ull) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < N; k++) {
       if (fx[k] <= 3390) x[k] = ab_to_xz_linear(fx[k]);
       if (fz[k] <= 3390) z[k] = ab_to_xz_linear(fz[k]);
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < N; k++) {
     // {x, z - kZoff} as int16 pair; x in [-361, 28027]
     const i16x2 xz = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm((uint32_t)(z[k] - kZoff), (uint32_t)x[k], 0x05040100u));
     constexpr i16x2 cb = {(short)kLabInv[0], (short)kLabInv[2]}, cg = {(short)kLabInv[3], (short)kLabInv[5]},

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Instruction ledger of the fused chain's frame loop (one 8-pixel item of one frame per trip), priced with the measured
+issue costs of tools/isa_cycles.py, for the kernel variants bench.py launches.  Writes profiles/chain_ledger.json (read by
+bench.py for the `roofline.valu` record) and prints the per-opcode tables (committed as profiles/rNN_chain_isa_ledger.txt).
+
+The frame loop is found in the hipcc -save-temps listing as the depth-2 loop of the kernel: every basic block LLVM annotates
+with "in Loop: Header=<frame loop header>" plus the header itself.  That is a STATIC count: blocks behind wave-uniform
+branches that the benchmark never takes (debayered tap, non-zero colour bias, abToXZ linear segment, image-edge fix-ups)
+are inside the loop too; they are listed separately by the marker instructions they contain and subtracted for the
+`executed` figure.  `--pmc-valu-per-wave N` (SQ_INSTS_VALU / SQ_WAVES of the same launch) cross-checks the executed count.
+
+usage: chain_ledger.py [--clock GHz] [--pmc workload=valu_per_wave,iterations_per_wave ...]"""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_cycles as ic  # noqa: E402
+
+# workload -> kernel variant substring (BITS, WB, threads): bench.py's configurations
+VARIANTS = {"config2": "chain_fast_kernelILi7ELi1ELi512E", "chain": "chain_fast_kernelILi7ELi0ELi512E",
+            "config3": "chain_fast_kernelILi8ELi2ELi256E", "config5": "chain_fast_kernelILi0ELi0ELi256E"}
+# blocks the benchmark never executes, recognised by an instruction only they contain
+RARE_MARKERS = [("abToXZ linear segment", re.compile(r"0x4ded21")), ("colour bias != 0", None), ("debayered tap", None)]
+LDS_CYCLES = {"ds_read_b32": 2, "ds_read_b64": 2, "ds_read_b128": 4, "ds_read_u8": 2, "ds_read_u16": 2, "ds_read2_b32": 4, "ds_read_b96": 8}
+
+
+def compile_listing(tmp):
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+             "-fno-slp-vectorize", "-D__HIP_PLATFORM_AMD__", "-x", "hip", "-c", os.path.join(ROOT, "raw_image_pipeline_amd", "csrc", "rip_chain.hip"),
+             "-save-temps", "-o", "chain.o"]
+    subprocess.run(["/opt/rocm/bin/hipcc"] + flags, cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return os.path.join(tmp, "rip_chain-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def loop_blocks(lines):
+    """Splits the kernel body into basic blocks and returns those of the deepest loop (the frame loop)."""
+    blocks, cur = [], {"label": "entry", "comment": "", "ins": []}
+    for l in lines:
+        m = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", l)
+        if m:
+            blocks.append(cur)
+            cur = {"label": m.group(1), "comment": m.group(2) or "", "ins": []}
+            continue
+        m = re.match(r"^; %bb\.\d+:\s*(;.*)?$", l)
+        if m:
+            blocks.append(cur)
+            cur = {"label": "", "comment": l, "ins": []}
+            continue
+        t = l.strip()
+        if l.startswith("\t") and t and t[0] not in ".;":
+            cur["ins"].append(t)
+        elif t.startswith(";") and "in Loop" in t or "Loop Header" in t or "Parent Loop" in t:
+            cur["comment"] += " " + t
+    blocks.append(cur)
+    depth = max([int(d) for b in blocks for d in re.findall(r"Depth=(\d+)", b["comment"])] or [0])
+    if depth == 0:
+        return blocks
+    hdr = None
+    for b in blocks:
+        if re.search(r"Loop Header: Depth=%d" % depth, b["comment"]):
+            hdr = b["label"].lstrip(".L")
+    return [b for b in blocks if re.search(r"Loop Header: Depth=%d" % depth, b["comment"]) or
+            ("Header=%s Depth=%d" % (hdr, depth)) in b["comment"]]
+
+
+def price(blocks):
+    cyc, cnt = collections.Counter(), collections.Counter()
+    lds = 0
+    for b in blocks:
+        for t in b["ins"]:
+            op = t.split()[0]
+            c = ic.cost(t)
+            key = op + (" [sgpr src]" if c == 4.3 and ic.FAST.match(op) else "")
+            cnt[key] += 1
+            cyc[key] += c
+            if op.startswith("ds_"):
+                lds += LDS_CYCLES.get(op, 2)
+    return cyc, cnt, lds
+
+
+def main():
+    clock = 2.1
+    pmc = {}
+    args = sys.argv[1:]
+    while args:
+        a = args.pop(0)
+        if a == "--clock":
+            clock = float(args.pop(0))
+        elif a == "--pmc":
+            while args and "=" in args[0]:
+                k, v = args.pop(0).split("=")
+                pmc[k] = [float(x) for x in v.split(",")]
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        listing = compile_listing(tmp)
+        for wl, pat in VARIANTS.items():
+            name, lines = ic.kernel_lines(listing, pat)
+            blocks = loop_blocks(lines)
+            rare = [b for b in blocks if any(re.search(r"0x4ded21", t) for t in b["ins"]) or
+                    sum(1 for t in b["ins"] if t.startswith("v_add_f32") and ic.SGPR_SRC.search(t.split(",", 1)[1])) >= 3 or
+                    sum(1 for t in b["ins"] if t.startswith("v_perm_b32")) >= 6 and any("buffer_store_dwordx3" in t for t in b["ins"])]
+            cyc, cnt, lds = price(blocks)
+            rcyc, rcnt, rlds = price(rare)
+            valu = sum(v for k, v in cnt.items() if k.startswith("v_"))
+            rvalu = sum(v for k, v in rcnt.items() if k.startswith("v_"))
+            tot, rtot = sum(cyc.values()), sum(rcyc.values())
+            rec = {"kernel": pat, "static_valu_instr": valu, "static_valu_cycles": round(tot, 1), "rare_valu_instr": rvalu,
+                   "rare_valu_cycles": round(rtot, 1), "valu_cycles_per_item": round(tot - rtot, 1), "valu_instr_per_item": valu - rvalu,
+                   "lds_instr_per_item": sum(v for k, v in cnt.items() if k.startswith("ds_")), "lds_cycles_per_item": lds - rlds,
+                   "salu_instr_per_item": sum(v for k, v in cnt.items() if k.startswith("s_")), "pixels_per_item": 8, "clock_GHz": clock}
+            if wl in pmc:
+                per_wave, iters = pmc[wl]
+                rec["pmc_valu_instr_per_item"] = round(per_wave / iters, 1)
+            out[wl] = rec
+            print("== %s: %s" % (wl, name[:100]))
+            print("   frame loop, static: %d VALU instructions, %.0f issue cycles; never-taken blocks: %d / %.0f; executed estimate: %d / %.0f"
+                  % (valu, tot, rvalu, rtot, valu - rvalu, tot - rtot))
+            print("   per pixel-wave: %.1f VALU issue cycles, %.1f LDS cycles (conflict-free), %d LDS / %d SALU instructions per item"
+                  % ((tot - rtot) / 8, (lds - rlds) / 8.0, rec["lds_instr_per_item"], rec["salu_instr_per_item"]))
+            for k, v in sorted(cyc.items(), key=lambda kv: -kv[1])[:28]:
+                if v:
+                    print("      %-36s n=%-4d cycles=%.0f" % (k, cnt[k], v))
+    with open(os.path.join(ROOT, "profiles", "chain_ledger.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+
+
+if __name__ == "__main__":
+    main()
