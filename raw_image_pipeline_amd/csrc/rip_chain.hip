@@ -114,9 +114,15 @@ template <int BITS, int WB>
 __device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const VigRegs& vr,
                                            const CcRegs& cc, const HsvRegs& hr, const float (&mask)[4], int (&q)[4][3]) {
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    apply_wb(WB, w, q[k][0], q[k][1], q[k][2]);
-    if constexpr ((BITS & ST_CC) != 0) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
+  for (int k = 0; k < 4; k++) apply_wb(WB, w, q[k][0], q[k][1], q[k][2]);
+  if constexpr ((BITS & ST_CC) != 0) {
+#if RIP_PK
+    apply_cc2(p, cc, q[0], q[1]);
+    apply_cc2(p, cc, q[2], q[3]);
+#else
+#pragma unroll
+    for (int k = 0; k < 4; k++) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
+#endif
   }
   if constexpr ((BITS & ST_VIG) != 0) {
 #pragma unroll
