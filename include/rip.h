@@ -134,6 +134,12 @@ rip_status rip_set_debug(rip_pipeline* p, int debug);                     /* cpp
 /* ---- setters (hpp:66-104; cpp:241-383) ---------------------------------------------------- */
 rip_status rip_set_debayer(rip_pipeline* p, int enabled);                         /* hpp:66 */
 rip_status rip_set_debayer_encoding(rip_pipeline* p, const char* encoding);       /* hpp:67 */
+/* Extension beyond the reference, off by default.  DebayerModule lists bayer_{rggb,bggr,gbrg,grbg}16 (debayer.hpp:73-80)
+ * and throws for them (debayer.cpp:76-78; so does this library).  With the extension on such frames (one channel of
+ * uint16, pitches in bytes) are demosaiced with the 8-bit path's formulas on 16-bit samples -- what cv::demosaicing does
+ * for CV_16UC1 -- and flipped; the result is 3 x uint16 per pixel, encoding "bgr16", rows * cols * 6 bytes.  Every other
+ * stage is an 8-bit stage in the reference and must be disabled (RIP_ERR_ASSERT otherwise); no taps are kept. */
+rip_status rip_set_debayer_16bit(rip_pipeline* p, int enabled);
 rip_status rip_set_flip(rip_pipeline* p, int enabled);                            /* hpp:69 */
 rip_status rip_set_flip_angle(rip_pipeline* p, int angle);                        /* hpp:70 */
 rip_status rip_set_white_balance(rip_pipeline* p, int enabled);                   /* hpp:72 */

@@ -86,6 +86,15 @@ def debayer(bayer, encoding):
     return out
 
 
+def debayer16(bayer, encoding):
+    """Extension: 16-bit Bayer frame (uint16, HxW) -> BGR uint16 with the 8-bit path's formulas."""
+    a = np.ascontiguousarray(bayer, np.uint16)
+    rows, cols = a.shape
+    out = np.empty((rows, cols, 3), np.uint16)
+    lib().ripo_debayer_bilinear16(a.ctypes.data_as(C.c_void_p), rows, cols, BAYER[encoding.replace("16", "8")], out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def swap_rb(img):
     img, p = _u8(img)
     out = np.empty_like(img)

@@ -96,6 +96,39 @@ void ripo_debayer_bilinear(const uint8_t* s, int rows, int cols, int pattern, ui
   memcpy(d + (size_t)(H - 1) * W * 3, d + (size_t)(H - 2) * W * 3, (size_t)W * 3);
 }
 
+/* 16-bit Bayer (extension beyond the reference, which rejects bayer_*16 at debayer.cpp:76-78): cv::demosaicing's
+ * Bayer2RGB_Invoker<ushort> runs the same two-tap / four-tap rounding averages and border replication on 16-bit
+ * samples; restated on uint16_t, output BGR interleaved. */
+void ripo_debayer_bilinear16(const uint16_t* s, int rows, int cols, int pattern, uint16_t* d) {
+  const int W = cols, H = rows;
+  for (int y = 1; y < H - 1; y++) {
+    for (int x = 1; x < W - 1; x++) {
+      const uint16_t* p = s + (size_t)y * W + x;
+      uint16_t* o = d + ((size_t)y * W + x) * 3;
+      int c = bayer_color(pattern, y, x);
+      if (c == 1) {
+        int h = ((int)p[-1] + p[1] + 1) >> 1;
+        int v = ((int)p[-W] + p[W] + 1) >> 1;
+        int ch = bayer_color(pattern, y, x + 1);
+        o[1] = p[0];
+        o[ch] = (uint16_t)h;
+        o[2 - ch] = (uint16_t)v;
+      } else {
+        int g = ((int)p[-1] + p[1] + p[-W] + p[W] + 2) >> 2;
+        int q = ((int)p[-W - 1] + p[-W + 1] + p[W - 1] + p[W + 1] + 2) >> 2;
+        o[c] = p[0];
+        o[1] = (uint16_t)g;
+        o[2 - c] = (uint16_t)q;
+      }
+    }
+    uint16_t* r = d + (size_t)y * W * 3;
+    memcpy(r, r + 3, 6);
+    memcpy(r + (size_t)(W - 1) * 3, r + (size_t)(W - 2) * 3, 6);
+  }
+  memcpy(d, d + (size_t)W * 3, (size_t)W * 6);
+  memcpy(d + (size_t)(H - 1) * W * 3, d + (size_t)(H - 2) * W * 3, (size_t)W * 6);
+}
+
 void ripo_swap_rb(const uint8_t* src, size_t npix, uint8_t* dst) {
   for (size_t i = 0; i < npix; i++) {
     uint8_t b = src[i * 3], g = src[i * 3 + 1], r = src[i * 3 + 2];

@@ -46,6 +46,8 @@ int ripo_bayer_pattern(const char* encoding);
 void ripo_debayer_bilinear(const uint8_t* bayer, int rows, int cols, int pattern, uint8_t* bgr);
 
 /* cvtColor(RGB2BGR) on a 3-channel image (debayer.cpp:72-73). In place allowed. */
+/* Extension (the reference rejects bayer_*16): the same bilinear demosaic on 16-bit samples, BGR out. */
+void ripo_debayer_bilinear16(const uint16_t* bayer, int rows, int cols, int pattern, uint16_t* bgr);
 void ripo_swap_rb(const uint8_t* src, size_t npix, uint8_t* dst);
 
 /* flip.cpp:37-58.  angle in {90,180,270}; any other value copies.  dst has

@@ -101,6 +101,7 @@ bool is_bayer16(const std::string& e) {
 // What one frame geometry/encoding turns into
 struct Plan {
   int src_kind = rip::SRC_BGR, ry = 0, rx = 0;
+  int elem_bytes = 1;     // 2: the 16-bit Bayer extension (debayer + flip only, bgr16 out)
   int channels = 3;       // channels after the debayer stage
   int flip_angle = 0;     // effective
   int mid_rows = 0, mid_cols = 0;  // post-flip geometry (pointwise chain output)
@@ -410,7 +411,16 @@ Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const st
     pl.channels = 3;
     pl.encoding_out = "bgr8";
   } else if (is_bayer16(encoding)) {
-    throw InvalidArgument("Encoding [" + encoding + "] is a valid pattern but is not supported!");
+    // debayer.cpp:76-78 throws for these names; rip_set_debayer_16bit(1) opts into the extension instead
+    if (!m.debayer_16bit) throw InvalidArgument("Encoding [" + encoding + "] is a valid pattern but is not supported!");
+    if (channels != 1) throw AssertError("cv::demosaicing: Bayer input must have one channel");
+    if (rows < 3 || cols < 3) throw AssertError("cv::demosaicing: image too small");
+    std::string e8 = encoding.substr(0, encoding.size() - 2) + "8";
+    parse_bayer(e8, pl.ry, pl.rx);
+    pl.src_kind = rip::SRC_BAYER;
+    pl.elem_bytes = 2;
+    pl.channels = 3;
+    pl.encoding_out = "bgr16";
   } else if (encoding == "rgb8") {
     if (channels != 3) throw AssertError("cvtColor(RGB2BGR): rgb8 input must have three channels");
     pl.src_kind = rip::SRC_RGB;  // swapped to BGR; the encoding string stays "rgb8" (debayer.cpp:72-73)
@@ -451,6 +461,11 @@ Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const st
   }
   if (m.ce_enabled && pl.channels == 3) pl.stage_bits |= rip::ST_HSV;
   pl.remap = m.und_enabled && m.und_available && m.dist_model != "none";
+  if (pl.elem_bytes == 2 && (pl.wb_mode != rip::WB_NONE || pl.stage_bits != 0 || pl.remap))
+    // every later module of the reference works on 8-bit images (cv::LUT, xphoto white balance, 8-bit Lab / HSV tables)
+    // and would assert on CV_16UC3
+    throw AssertError("16-bit Bayer frames go through debayer and flip only: disable white balance, colour calibration, gamma, "
+                      "vignetting, colour enhancer and undistortion (they are 8-bit stages)");
   pl.out_rows = pl.remap ? m.dist_h : pl.mid_rows;
   pl.out_cols = pl.remap ? m.dist_w : pl.mid_cols;
   return pl;
@@ -460,6 +475,28 @@ Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const st
 void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_step, size_t in_frame_stride, int n, int rows,
                int cols, uint8_t* d_out, size_t out_step, size_t out_frame_stride, uint8_t* d_tap_deb, uint8_t* d_tap_col) {
   DeviceGuard device_guard(p->device);
+  if (pl.elem_bytes == 2) {  // 16-bit Bayer extension: one kernel, no taps
+    rip::Debayer16Params d = {};
+    d.src = d_in;
+    d.src_step = in_step;
+    d.src_frame_stride = in_frame_stride;
+    d.rows = rows;
+    d.cols = cols;
+    d.bayer_ry = pl.ry;
+    d.bayer_rx = pl.rx;
+    d.dst = d_out;
+    d.dst_step = out_step ? out_step : (size_t)pl.out_cols * 6;
+    d.dst_frame_stride = out_frame_stride ? out_frame_stride : d.dst_step * pl.out_rows;
+    d.drows = pl.out_rows;
+    d.dcols = pl.out_cols;
+    d.flip_angle = pl.flip_angle;
+    d.n_frames = n;
+    ProfScope ps(p, RIP_KERNEL_CHAIN);
+    rip::launch_debayer16(d, p->stream);
+    hipError_t le16 = hipGetLastError();
+    if (le16 != hipSuccess) throw DeviceError(std::string("kernel launch failed: ") + hipGetErrorString(le16));
+    return;
+  }
   ensure_tables(p);
   const size_t tap_pitch = (size_t)pl.mid_cols * pl.channels;  // taps are tightly packed API outputs
   const size_t tap_frame = tap_pitch * pl.mid_rows;
@@ -811,19 +848,21 @@ rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, s
     if (n_frames < 0) throw InvalidArgument("negative frame count");
     if (n_frames == 0) return;
     Plan pl = make_plan(p, rows, cols, channels, encoding);
-    if (in_step == 0) in_step = (size_t)cols * channels;
+    const size_t eb = (size_t)pl.elem_bytes;
+    if (in_step == 0) in_step = (size_t)cols * channels * eb;
     if (in_frame_stride == 0) in_frame_stride = in_step * rows;
-    if (in_step < (size_t)cols * channels) throw InvalidArgument("input row pitch smaller than a row");
+    if (in_step < (size_t)cols * channels * eb) throw InvalidArgument("input row pitch smaller than a row");
+    if (eb == 2 && (d_tap_debayered || d_tap_color)) throw InvalidArgument("16-bit Bayer frames have no taps");
     // several kernels put the frame index on gridDim.y (<= 65535): longer batches go through in slices.  The
     // frames of a stream are processed in order either way (the ccc Kalman state lives on the device).
     constexpr int kMaxFramesPerLaunch = 16384;
-    const size_t o_step = out_step ? out_step : (size_t)pl.out_cols * pl.channels;
+    const size_t o_step = out_step ? out_step : (size_t)pl.out_cols * pl.channels * eb;
     const size_t o_stride = out_frame_stride ? out_frame_stride : o_step * pl.out_rows;
     // the kernels address one frame with 32-bit byte offsets and 24-bit row multiplies: refuse pitches they cannot
     // express (and pitches that would make rows or frames overlap) instead of writing somewhere else
-    if (o_step < (size_t)pl.out_cols * pl.channels) throw InvalidArgument("output row pitch smaller than a row");
+    if (o_step < (size_t)pl.out_cols * pl.channels * eb) throw InvalidArgument("output row pitch smaller than a row");
     if (o_stride < o_step * (size_t)pl.out_rows) throw InvalidArgument("output frame stride smaller than a frame");
-    if (in_frame_stride < in_step * (size_t)(rows - 1) + (size_t)cols * channels) throw InvalidArgument("input frame stride smaller than a frame");
+    if (in_frame_stride < in_step * (size_t)(rows - 1) + (size_t)cols * channels * eb) throw InvalidArgument("input frame stride smaller than a frame");
     if (in_step >= (1u << 24) || o_step >= (1u << 24) || (unsigned long long)in_step * rows >= (1ull << 32) ||
         (unsigned long long)o_step * pl.out_rows >= (1ull << 32))
       throw InvalidArgument("row pitch too large: pitches must stay below 16 MiB and a frame below 4 GiB");
@@ -846,25 +885,26 @@ rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, 
     if (!image || !out || !encoding) throw InvalidArgument("null buffer or encoding");
     Plan pl = make_plan(p, rows, cols, channels, encoding);
     DeviceGuard device_guard(p->device);
-    if (step == 0) step = (size_t)cols * channels;
-    const size_t in_pitch = ((size_t)cols * channels + 3) & ~(size_t)3;  // dword-aligned rows on the device
+    const size_t eb = (size_t)pl.elem_bytes;
+    if (step == 0) step = (size_t)cols * channels * eb;
+    const size_t in_pitch = ((size_t)cols * channels * eb + 3) & ~(size_t)3;  // dword-aligned rows on the device
     const size_t in_bytes = in_pitch * rows;
-    const size_t out_bytes = (size_t)pl.out_rows * pl.out_cols * pl.channels;
+    const size_t out_bytes = (size_t)pl.out_rows * pl.out_cols * pl.channels * eb;
     const size_t mid_bytes = (size_t)pl.mid_rows * pl.mid_cols * pl.channels;
     if (out_capacity < out_bytes) throw CapacityError("output buffer too small: need " + std::to_string(out_bytes) + " bytes");
     p->d_in.reserve(in_bytes);
     p->d_out.reserve(out_bytes);
     uint8_t* tap_deb = nullptr;
     uint8_t* tap_col = nullptr;
-    if (p->tap_mask & RIP_TAP_DEBAYERED) {
+    if ((p->tap_mask & RIP_TAP_DEBAYERED) && eb == 1) {
       p->d_tap_deb.reserve(mid_bytes);
       tap_deb = p->d_tap_deb.as<uint8_t>();
     }
-    if (p->tap_mask & RIP_TAP_COLOR) {
+    if ((p->tap_mask & RIP_TAP_COLOR) && eb == 1) {
       p->d_tap_col.reserve(mid_bytes);
       tap_col = p->d_tap_col.as<uint8_t>();
     }
-    HIP_CHECK(hipMemcpy2DAsync(p->d_in.ptr, in_pitch, image, step, (size_t)cols * channels, (size_t)rows, hipMemcpyHostToDevice, p->stream));
+    HIP_CHECK(hipMemcpy2DAsync(p->d_in.ptr, in_pitch, image, step, (size_t)cols * channels * eb, (size_t)rows, hipMemcpyHostToDevice, p->stream));
     run_batch(p, pl, p->d_in.as<uint8_t>(), in_pitch, in_bytes, 1, rows, cols, p->d_out.as<uint8_t>(), 0, 0, tap_deb, tap_col);
     HIP_CHECK(hipMemcpyAsync(out, p->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, p->stream));
     HIP_CHECK(hipStreamSynchronize(p->stream));
@@ -878,7 +918,7 @@ rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, 
     };
     remember(RIP_IMAGE_DEBAYERED, &p->d_tap_deb, pl.mid_rows, pl.mid_cols, tap_deb != nullptr);
     remember(RIP_IMAGE_COLOR, &p->d_tap_col, pl.mid_rows, pl.mid_cols, tap_col != nullptr);
-    remember(RIP_IMAGE_PROCESSED, &p->d_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0);
+    remember(RIP_IMAGE_PROCESSED, &p->d_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0 && eb == 1);
     if (out_rows) *out_rows = pl.out_rows;
     if (out_cols) *out_cols = pl.out_cols;
     if (out_channels) *out_channels = pl.channels;
@@ -1023,6 +1063,7 @@ rip_status rip_set_debug(rip_pipeline* p, int v) {
   }
 
 RIP_SETTER(rip_set_debayer, (rip_pipeline * p, int v), p->m.debayer_enabled = v != 0)
+RIP_SETTER(rip_set_debayer_16bit, (rip_pipeline * p, int v), p->m.debayer_16bit = v != 0)
 RIP_SETTER(rip_set_debayer_encoding, (rip_pipeline * p, const char* s), if (!s) throw InvalidArgument("null string"); p->m.debayer_encoding = s)
 RIP_SETTER(rip_set_flip, (rip_pipeline * p, int v), p->m.flip_enabled = v != 0)
 RIP_SETTER(rip_set_flip_angle, (rip_pipeline * p, int a), p->m.flip_angle = a)

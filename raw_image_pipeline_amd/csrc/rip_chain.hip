@@ -51,6 +51,43 @@ __global__ __launch_bounds__(kBlock) void chain_generic_kernel(ChainParams p) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// 16-bit Bayer extension: one thread per destination pixel (a feature path, not a tuned one): the same two-tap / four-tap
+// rounding averages and border rule as debayer_at on 16-bit samples (cv::demosaicing's Bayer2RGB_Invoker<ushort>), flip.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void debayer16_kernel(Debayer16Params p) {
+  const int frame = blockIdx.y;
+  const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
+  uint8_t* dst = p.dst + (size_t)frame * p.dst_frame_stride;
+  const long long npix = (long long)p.drows * p.dcols;
+  auto at = [&](int y, int x) { return (int)*reinterpret_cast<const uint16_t*>(src + (size_t)y * p.src_step + (size_t)x * 2); };
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npix; i += (long long)gridDim.x * kBlock) {
+    const int yd = (int)(i / p.dcols), xd = (int)(i - (long long)yd * p.dcols);
+    int ys, xs;
+    unflip(p.flip_angle, p.rows, p.cols, yd, xd, ys, xs);
+    const int y = clampi(ys, 1, p.rows - 2), x = clampi(xs, 1, p.cols - 2);  // border: the interior formula at the clamped position
+    const int dy = (y - p.bayer_ry) & 1, dx = (x - p.bayer_rx) & 1;           // (0,0): R site, (1,1): B site
+    const int c = at(y, x);
+    int b, g, r;
+    if (dy != dx) {
+      const int h = (at(y, x - 1) + at(y, x + 1) + 1) >> 1, v = (at(y - 1, x) + at(y + 1, x) + 1) >> 1;
+      g = c;
+      r = dy == 0 ? h : v;
+      b = dy == 0 ? v : h;
+    } else {
+      const int x4 = (at(y, x - 1) + at(y, x + 1) + at(y - 1, x) + at(y + 1, x) + 2) >> 2;
+      const int d4 = (at(y - 1, x - 1) + at(y - 1, x + 1) + at(y + 1, x - 1) + at(y + 1, x + 1) + 2) >> 2;
+      g = x4;
+      r = dy == 0 ? c : d4;
+      b = dy == 0 ? d4 : c;
+    }
+    uint16_t* o = reinterpret_cast<uint16_t*>(dst + (size_t)yd * p.dst_step + (size_t)xd * 6);
+    o[0] = (uint16_t)b;
+    o[1] = (uint16_t)g;
+    o[2] = (uint16_t)r;
+  }
+}
+
 // Tables of the fast kernel in LDS: only what the compile-time stage set reads.
 template <bool ON, typename T>
 struct OptTab {
@@ -483,6 +520,12 @@ static int frame_groups(const ChainParams& p, int cap, int blocks) {
   const int frames_per_visit = std::max(1, tune_int("RIP_CHAIN_FRAMES", valu_bound ? 16 : 1));
   const int groups = std::max(cap / std::max(blocks, 1), (p.n_frames + frames_per_visit - 1) / frames_per_visit);
   return std::max(1, std::min(p.n_frames, groups));
+}
+
+void launch_debayer16(const Debayer16Params& p, hipStream_t stream) {
+  if (p.n_frames <= 0) return;
+  const long long npix = (long long)p.drows * p.dcols;
+  hipLaunchKernelGGL(debayer16_kernel, dim3(grid_blocks_for(npix, 4096), p.n_frames), dim3(kBlock), 0, stream, p);
 }
 
 void launch_chain(const ChainParams& p, hipStream_t stream) {

@@ -50,6 +50,7 @@ struct Modules {
   // DebayerModule (debayer.hpp:70-72): enable flag stored but ignored by apply (:38-40)
   bool debayer_enabled = true;
   std::string debayer_encoding = "auto";
+  bool debayer_16bit = false;  // extension (rip_set_debayer_16bit): accept bayer_*16 instead of throwing like the reference
   // FlipModule (flip.hpp:63-66)
   bool flip_enabled = false;
   int flip_angle = 0;

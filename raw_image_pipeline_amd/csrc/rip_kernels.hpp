@@ -89,6 +89,17 @@ struct ChainParams {
   const DevTables* tabs;
 };
 
+// 16-bit Bayer extension (the reference lists bayer_*16 and rejects them, debayer.hpp:73-80 / debayer.cpp:76-78):
+// bilinear demosaic on 16-bit samples + flip, BGR16 out.  Pitches and strides in BYTES.
+struct Debayer16Params {
+  const uint8_t* src;
+  size_t src_step, src_frame_stride;
+  int rows, cols, bayer_ry, bayer_rx;
+  uint8_t* dst;
+  size_t dst_step, dst_frame_stride;
+  int drows, dcols, flip_angle, n_frames;
+};
+
 struct StatsParams {
   const uint8_t* src;
   size_t src_step, src_frame_stride;
@@ -160,6 +171,7 @@ struct RemapTiledParams {
 // Returns false (and launches nothing) when the geometry does not qualify for the tiled kernel.
 bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream);
 void launch_chain(const ChainParams& p, hipStream_t stream);
+void launch_debayer16(const Debayer16Params& p, hipStream_t stream);
 void launch_stats(const StatsParams& p, hipStream_t stream);
 void launch_ccc_estimate(const CccParams& p, hipStream_t stream);
 // Turns raw statistics into FrameWb (grey-world / pca) or runs the ccc temporal filter + gains.

@@ -137,18 +137,21 @@ class RawImagePipeline:
     def process(self, image, encoding):
         """cv::Mat process(const cv::Mat&, std::string&): returns a new array; input untouched."""
         img = np.asarray(image)
-        if img.dtype != np.uint8 or img.ndim not in (2, 3):
-            raise ValueError("image must be uint8, HxW or HxWxC")
-        if img.strides[-1] != 1 or (img.ndim == 3 and img.strides[1] != img.shape[2]):
+        wide = img.dtype == np.uint16  # 16-bit Bayer extension (set_debayer_16bit): uint16 in, uint16 BGR out
+        if img.dtype not in (np.uint8, np.uint16) or img.ndim not in (2, 3):
+            raise ValueError("image must be uint8 (or uint16 Bayer), HxW or HxWxC")
+        if img.strides[-1] != img.itemsize or (img.ndim == 3 and img.strides[1] != img.shape[2] * img.itemsize):
             img = np.ascontiguousarray(img)
         rows, cols = img.shape[:2]
         cn = 1 if img.ndim == 2 else img.shape[2]
-        orows, ocols, ocn, _ = self.query_output(rows, cols, cn, encoding)
-        out = np.empty(orows * ocols * ocn, np.uint8)
+        orows, ocols, ocn, oenc = self.query_output(rows, cols, cn, encoding)
+        if wide != oenc.endswith("16"):
+            raise ValueError("dtype %s does not match encoding %s" % (img.dtype, encoding))
+        out = np.empty(orows * ocols * ocn, np.uint16 if wide else np.uint8)
         r, c, k = C.c_int(), C.c_int(), C.c_int()
         enc = C.create_string_buffer(32)
         self._call("rip_apply", img.ctypes.data_as(C.c_void_p), rows, cols, cn, C.c_size_t(img.strides[0]),
-                   encoding.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(r), C.byref(c),
+                   encoding.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes), C.byref(r), C.byref(c),
                    C.byref(k), enc)
         self.last_encoding = enc.value.decode()
         return out.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
@@ -278,6 +281,10 @@ class RawImagePipeline:
     # ---- setters (names as in raw_image_pipeline_python.cpp:25-58) --------------------------------
     def set_debayer(self, enabled):
         self._call("rip_set_debayer", int(bool(enabled)))
+
+    def set_debayer_16bit(self, enabled):
+        """Extension: accept bayer_*16 frames (debayer + flip only, bgr16 out) instead of raising like the reference."""
+        self._call("rip_set_debayer_16bit", int(bool(enabled)))
 
     def set_debayer_encoding(self, encoding):
         self._call("rip_set_debayer_encoding", encoding.encode())

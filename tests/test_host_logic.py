@@ -238,3 +238,22 @@ def test_load_params_recreates_the_modules_like_the_reference(host_pipe):
     p.load_params(os.path.join(CFG, "params_full.yaml"))
     assert np.array_equal(p.get_color_calibration_matrix(), np.eye(3))
     assert p.is_undistortion_enabled() and p.query_output(40, 56, 3, "bgr8")[:2] == (40, 56)    # no calibration any more
+
+
+def test_16bit_bayer_extension_is_opt_in(host_pipe):
+    """bayer_*16 raise exactly like the reference (debayer.cpp:76-78) unless rip_set_debayer_16bit(1) opts into the extension;
+    with it the frame takes debayer + flip only and comes out as bgr16; any 8-bit stage left enabled is an error."""
+    p = host_pipe
+    p.set_white_balance(False)
+    p.set_undistortion(False)
+    with pytest.raises(ValueError, match="valid pattern but is not supported"):
+        p.query_output(48, 64, 1, "bayer_gbrg16")
+    p.set_debayer_16bit(True)
+    assert p.query_output(48, 64, 1, "bayer_gbrg16") == (48, 64, 3, "bgr16")
+    p.set_flip(True)
+    p.set_flip_angle(90)
+    assert p.query_output(48, 64, 1, "bayer_rggb16") == (64, 48, 3, "bgr16")
+    p.set_gamma_correction(True)
+    with pytest.raises(Exception, match="8-bit stages"):
+        p.query_output(48, 64, 1, "bayer_rggb16")
+    assert p.query_output(48, 64, 1, "bayer_rggb8") == (64, 48, 3, "bgr8")  # 8-bit frames are unaffected

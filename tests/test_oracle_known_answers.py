@@ -32,13 +32,25 @@ def hand_debayer(bayer, pattern):
     out[:, -1] = out[:, -2]
     out[0] = out[1]
     out[-1] = out[-2]
-    return out.astype(np.uint8)
+    return out.astype(bayer.dtype)
 
 
 @pytest.mark.parametrize("pattern", sorted(synth.PATTERNS))
 def test_debayer_matches_hand_transcription(oracle, pattern):
     bayer = np.random.default_rng(1).integers(0, 256, (12, 14), dtype=np.uint8)
     assert np.array_equal(oracle.debayer(bayer, pattern), hand_debayer(bayer, pattern))
+
+
+@pytest.mark.parametrize("pattern", sorted(synth.PATTERNS))
+def test_debayer16_matches_hand_transcription(oracle, pattern):
+    """The 16-bit extension (the reference rejects bayer_*16): same rule on uint16, incl. values whose sums need 18 bits."""
+    bayer = np.random.default_rng(3).integers(0, 65536, (12, 14)).astype(np.uint16)
+    bayer[4:6, 4:8] = 65535
+    got = oracle.debayer16(bayer, pattern.replace("8", "16"))
+    assert got.dtype == np.uint16 and np.array_equal(got, hand_debayer(bayer, pattern))
+    # 8-bit data in 16-bit containers goes through unchanged: the rule does not depend on the sample width
+    b8 = np.random.default_rng(4).integers(0, 256, (10, 12), dtype=np.uint8)
+    assert np.array_equal(oracle.debayer16(b8.astype(np.uint16), pattern.replace("8", "16")), oracle.debayer(b8, pattern))
 
 
 def test_debayer_constant_colour_planes(oracle):

@@ -436,6 +436,39 @@ def test_config5_full_size_3840x2160_debayer_undistort(gpu_pipe, oracle):
     run_both(gpu_pipe, oracle, c, frame, "bayer_rggb8", TOL_INTERP, what="config5 3840x2160")
 
 
+@pytest.mark.parametrize("pattern", PATTERNS)
+@pytest.mark.parametrize("size,angle", [((64, 48), 0), ((37, 29), 180), ((50, 38), 90), ((6, 4), 270), ((3, 3), 0)])
+def test_16bit_bayer_extension(gpu_pipe, oracle, pattern, size, angle):
+    """rip_set_debayer_16bit: uint16 Bayer -> bgr16 through the C-ABI against the oracle's 16-bit demosaic + flip
+    (bit-exact), through the host path and as a resident batch."""
+    import torch
+    w, h = size
+    rng = np.random.default_rng(w * 100 + h + angle)
+    frame = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    enc = pattern.replace("8", "16")
+    configure(gpu_pipe, cfg(flip=angle != 0, flip_angle=angle))
+    gpu_pipe.set_debayer_16bit(True)
+    got = gpu_pipe.process(frame, enc)
+    ref = oracle.debayer16(frame, enc)
+    if angle:
+        ref = oracle.flip(ref.view(np.uint8).reshape(h, w, 6), angle)
+        ref = np.ascontiguousarray(ref).view(np.uint16).reshape(ref.shape[0], ref.shape[1], 3)
+    assert got.dtype == np.uint16 and gpu_pipe.last_encoding == "bgr16"
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    batch = torch.from_numpy(np.stack([frame, frame[::-1].copy()]).view(np.uint8).reshape(2, h, w * 2)).cuda()
+    # resident batch: uint8 view of the uint16 rows (pitch in bytes), [n, rows, cols * 2] in, [n, R, C * 6] bytes out
+    out = torch.empty((2,) + (ref.shape[0], ref.shape[1] * 6), dtype=torch.uint8, device="cuda")
+    gpu_pipe._call("rip_apply_device", __import__("ctypes").c_void_p(batch.data_ptr()), __import__("ctypes").c_size_t(w * 2),
+                   __import__("ctypes").c_size_t(h * w * 2), 2, h, w, 1, enc.encode(), __import__("ctypes").c_void_p(out.data_ptr()),
+                   __import__("ctypes").c_size_t(0), __import__("ctypes").c_size_t(0), None, None)
+    torch.cuda.synchronize()
+    out0 = out[0].cpu().numpy().view(np.uint16).reshape(ref.shape)
+    assert np.array_equal(out0, ref)
+    gpu_pipe.set_debayer_16bit(False)
+    with pytest.raises(ValueError, match="valid pattern but is not supported"):
+        gpu_pipe.process(frame, enc)
+
+
 def test_error_behaviour(gpu_pipe):
     frame = synth.gen_frame(64, 48)
     configure(gpu_pipe, cfg())
