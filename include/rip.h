@@ -222,6 +222,9 @@ int rip_get_table(rip_pipeline* p, int which, int32_t* out, int capacity);
  * vignetting_correction.cpp:32-63) for a rows x cols frame with the handle's current scale / a2 / a4:
  * rows * cols floats, row-major.  Host computation only; works on RIP_DEVICE_NONE handles. */
 rip_status rip_get_vignetting_mask(rip_pipeline* p, int rows, int cols, float* out, size_t capacity_floats);
+/* Test hook: the double-double atan the device map builder uses (rip_maps.hip), evaluated on the device for n doubles;
+ * the parity tests compare it with libm's over the range fisheye maps reach. */
+rip_status rip_debug_atan(rip_pipeline* p, const double* in, double* out, int n);
 const char* rip_version(void);
 
 #ifdef __cplusplus

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librip_hip.so")
-SOURCES = ["rip_chain.hip", "rip_stats.hip", "rip_ccc.hip", "rip_remap.hip", "rip_host.cpp", "rip_api.cpp"]  # compiled in parallel
+SOURCES = ["rip_chain.hip", "rip_stats.hip", "rip_ccc.hip", "rip_remap.hip", "rip_maps.hip", "rip_host.cpp", "rip_api.cpp"]  # compiled in parallel
 HEADERS = ["rip_kernels.hpp", "rip_device.hpp", "rip_tile.hpp", "rip_host.hpp", os.path.join("..", "..", "include", "rip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]

@@ -206,12 +206,41 @@ void und_init(rip_pipeline* p) {
   p->map_dirty = true;
 }
 
+// Where the maps are built: on the device for device handles (rip_maps.hip: one thread per map row, FP64, double-double
+// atan -- milliseconds instead of 0.25-0.5 s of host threads per calibration change), on the host for RIP_DEVICE_NONE handles
+// and when RIP_MAPS_ON_HOST is set (A/B and debugging).  Both produce the same floats (tests/test_parity_gpu.py).
+bool maps_on_device(const rip_pipeline* p) {
+  if (p->device == RIP_DEVICE_NONE) return false;
+  const char* e = std::getenv("RIP_MAPS_ON_HOST");
+  return !(e && *e && *e != '0');
+}
+
 void ensure_host_maps(rip_pipeline* p) {
   if (!p->map_dirty) return;
   const rip::Modules& m = p->m;
   if (m.dist_w <= 0 || m.dist_h <= 0) throw AssertError("undistortion: image size is not set");
-  p->h_map.resize((size_t)m.dist_w * m.dist_h * 2);
+  const size_t n = (size_t)m.dist_w * m.dist_h * 2;
+  p->h_map.resize(n);
   // maps have the *dist* image size even after setNewImageSize (undistortion.cpp:216)
+  if (maps_on_device(p)) {
+    DeviceGuard device_guard(p->device);
+    rip::FisheyeMapParams fp = {};
+    std::memcpy(fp.K, m.dist_K, sizeof(fp.K));
+    std::memcpy(fp.D, m.dist_D, sizeof(fp.D));
+    rip::fisheye_inverse_PR(m.rect_K, m.dist_R, fp.iR);
+    fp.w = m.dist_w;
+    fp.h = m.dist_h;
+    p->d_map.reserve(n * sizeof(float));
+    fp.map_xy = p->d_map.as<float>();
+    rip::launch_fisheye_maps(fp, p->stream);
+    // the host copy feeds the remap-plan compiler and rip_get_undistortion_maps
+    HIP_CHECK(hipMemcpyAsync(p->h_map.data(), p->d_map.ptr, n * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->map_dirty = false;
+    p->map_uploaded = true;
+    p->plan.valid = false;
+    return;
+  }
   rip::fisheye_init_undistort_rectify_map(m.dist_K, m.dist_D, m.dist_R, m.rect_K, m.dist_w, m.dist_h, p->h_map.data());
   p->map_dirty = false;
   p->map_uploaded = false;
@@ -1229,6 +1258,24 @@ rip_status rip_profile_end(rip_pipeline* p, double ms_sum[RIP_KERNEL_COUNT], int
     p->prof_on = false;
     p->prof_used = 0;
     p->prof_ids.clear();
+  });
+}
+
+rip_status rip_debug_atan(rip_pipeline* p, const double* in, double* out, int n) {
+  if (!p) return RIP_ERR_INVALID_ARGUMENT;
+  return guarded(p, [&] {
+    need_device(p);
+    if (!in || !out || n < 0) throw InvalidArgument("bad arguments");
+    DeviceGuard device_guard(p->device);
+    DevBuf a, b;
+    a.reserve((size_t)n * 8 + 8);
+    b.reserve((size_t)n * 8 + 8);
+    HIP_CHECK(hipMemcpyAsync(a.ptr, in, (size_t)n * 8, hipMemcpyHostToDevice, p->stream));
+    rip::launch_atan_probe(a.as<double>(), b.as<double>(), n, p->stream);
+    HIP_CHECK(hipMemcpyAsync(out, b.ptr, (size_t)n * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    a.release();
+    b.release();
   });
 }
 

@@ -666,6 +666,11 @@ void fisheye_estimate_new_camera_matrix(const double K[9], const double D[4], in
   std::memcpy(newK, out, sizeof(out));
 }
 
+void fisheye_inverse_PR(const double P[9], const double R[9], double iR_out[9]) {
+  const Mat3 iR = inverse3(mul3(P, R));
+  for (int i = 0; i < 9; i++) iR_out[i] = iR.v[i];
+}
+
 void fisheye_init_undistort_rectify_map(const double K[9], const double D[4], const double R[9],
                                         const double P[9], int w, int h, float* map_xy) {
   Mat3 iR = inverse3(mul3(P, R));

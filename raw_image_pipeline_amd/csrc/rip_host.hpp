@@ -122,6 +122,8 @@ void build_vignette_mask(int rows, int cols, double scale, double a2, double a4,
 void fisheye_estimate_new_camera_matrix(const double K[9], const double D[4], int w, int h, const double R[9],
                                         double balance, int new_w, int new_h, double fov_scale, double newK[9]);
 // Interleaved float2 map (x,y per destination pixel), w*h*2 floats.
+// iR = (P R)^-1 of initUndistortRectifyMap (adjugate inverse), shared by the host builder and the device kernel
+void fisheye_inverse_PR(const double P[9], const double R[9], double iR_out[9]);
 void fisheye_init_undistort_rectify_map(const double K[9], const double D[4], const double R[9],
                                         const double P[9], int w, int h, float* map_xy);
 

@@ -167,6 +167,15 @@ struct RemapTiledParams {
   int stages;                  // set by the launcher (ring kernel): LDS ring size, prefetch distance = stages - 1
 };
 
+// Fisheye maps on the device (rip_maps.hip): iR = (P R)^-1 from the host, K / D of the distorted camera.
+struct FisheyeMapParams {
+  double K[9], D[4], iR[9];
+  int w, h;
+  float* map_xy;  // [h][w] interleaved (x, y)
+};
+void launch_fisheye_maps(const FisheyeMapParams& p, hipStream_t stream);
+void launch_atan_probe(const double* in, double* out, int n, hipStream_t stream);  // test hook: the kernel's atan
+
 // ---- launchers (asynchronous on `stream`) -------------------------------------------------------
 // Returns false (and launches nothing) when the geometry does not qualify for the tiled kernel.
 bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream);

@@ -496,6 +496,13 @@ class RawImagePipeline:
         self._call("rip_profile_end", ms, cnt)
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
 
+    def debug_atan(self, values):
+        """atan of the device map builder (double-double, rip_maps.hip) for an array of doubles."""
+        a = np.ascontiguousarray(values, np.float64)
+        out = np.empty_like(a)
+        self._check(self._lib.rip_debug_atan(self._h, a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), int(a.size)))
+        return out
+
     def get_vignetting_mask(self, rows, cols):
         """Host-built mask plane of precomputeVignettingMask (vignetting_correction.cpp:32-63)."""
         out = np.empty((int(rows), int(cols)), np.float32)

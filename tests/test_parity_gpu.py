@@ -469,6 +469,62 @@ def test_16bit_bayer_extension(gpu_pipe, oracle, pattern, size, angle):
         gpu_pipe.process(frame, enc)
 
 
+def test_device_atan_is_correctly_rounded(gpu_pipe):
+    """The map builder's double-double atan (rip_maps.hip) over the range fisheye maps reach (r = tan of the incidence
+    angle: 0 .. a few), dense near 0 and 1 and at the table nodes k/16.  It agrees with libm's atan except where libm's is
+    not the correctly rounded result (glibc 2.35: about 0.1 % of the arguments are off by one ulp); every disagreement is
+    settled by an 80-digit evaluation, and the device value must be the nearest double each time.  A one-ulp difference
+    in theta moves a map coordinate by 2^-53 relative, i.e. changes the float map with probability 2^-29 per such pixel:
+    test_device_maps_equal_host_and_oracle_maps checks the maps themselves."""
+    import os
+    import sys
+    from decimal import Decimal as D
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        import gen_atan_table as gen
+    rng = np.random.default_rng(5)
+    r = np.concatenate([rng.uniform(0, 1, 400000), rng.uniform(1, 6, 300000), rng.uniform(0, 1e-3, 50000), 1 + rng.uniform(-1e-6, 1e-6, 50000),
+                        np.arange(0, 97) / 16.0, np.arange(1, 97) / 16.0 + 2.0 ** -40, 10.0 ** rng.uniform(-12, 6, 100000),
+                        [0.0, 1.0, 1e300]])
+    got = gpu_pipe.debug_atan(r)
+    want = np.arctan(r)
+    ulps = np.abs(got.view(np.int64) - want.view(np.int64))
+    assert ulps.max() <= 1
+    bad = np.flatnonzero(ulps)
+    assert bad.size <= 0.005 * r.size, bad.size
+    half_pi = gen.atan_dec(1) * 2
+    for i in bad[:: max(1, bad.size // 200)]:
+        x = D(float(r[i]))
+        true = gen.atan_dec(x) if x <= 1 else half_pi - gen.atan_dec(1 / x)
+        assert abs(D(float(got[i])) - true) < abs(D(float(want[i])) - true), (float(r[i]), float(got[i]), float(want[i]))
+
+
+@pytest.mark.parametrize("size", [(2448, 2048), (1920, 1200), (3840, 2160), (131, 97)])
+def test_device_maps_equal_host_and_oracle_maps(gpu_pipe, rip_lib, oracle, monkeypatch, size):
+    """undistortion.cpp:212-220 on the device (one thread per map row, FP64, double-double atan) against the host builder
+    and the oracle's independent one, at the three BASELINE sizes and an odd one, two cameras each: every map float identical."""
+    from raw_image_pipeline_amd import RawImagePipeline
+    w, h = size
+    for balance, fov in ((0.0, 1.0), (0.6, 1.3)):
+        cam = synth.camera_model(w, h)
+        synth.load_camera(gpu_pipe, cam)
+        gpu_pipe.set_undistortion_balance(balance)
+        gpu_pipe.set_undistortion_fov_scale(fov)
+        mx, my = gpu_pipe.get_undistortion_maps()
+        host = RawImagePipeline(False, "", "", "", device=-1)
+        synth.load_camera(host, cam)
+        host.set_undistortion_balance(balance)
+        host.set_undistortion_fov_scale(fov)
+        hx, hy = host.get_undistortion_maps()
+        assert np.array_equal(mx.view(np.uint32), hx.view(np.uint32)) and np.array_equal(my.view(np.uint32), hy.view(np.uint32))
+        c = cfg(undistort=True, cam=cam, balance=balance, fov_scale=fov)
+        from helpers import oracle_maps
+        ox, oy = oracle_maps(oracle, c)
+        assert np.array_equal(mx.view(np.uint32), ox.view(np.uint32)) and np.array_equal(my.view(np.uint32), oy.view(np.uint32))
+
+
 def test_error_behaviour(gpu_pipe):
     frame = synth.gen_frame(64, 48)
     configure(gpu_pipe, cfg())
