@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--workload", default="config2", choices=["config2", "chain", "config3", "config5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true", help="skip the streaming copy/read microbenchmark")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run this command under rocprofv3 --pmc for roofline.traffic "
+                    "(the committed profiles/pmc_traffic.json figure is reported instead, labelled as such)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     return ap.parse_args()
 
@@ -188,6 +190,45 @@ def cpu_baseline(width, height, pattern, seconds):
             "sample": "%d frames of the same %dx%d %s full chain through the oracle (CPU restatement of the OpenCV path; OpenCV "
                       "itself is not installable here), reference-faithful and tight schedules, 1 thread (median of <= 20 frames) "
                       "and %d threads x 1 frame (median round), %.1f s" % (total_frames, width, height, pattern, cores, total_s)}
+
+
+def live_pmc_traffic(args, kernel_class):
+    """HBM bytes of one launch of the dominant kernel class, measured NOW: this very command (same workload, same batch, 3
+    steps) re-run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, KiB units, x2 on FETCH_SIZE for
+    gfx950's 128-byte requests tallied at 64 B, as MI355X_MICROARCH.md prescribes (tools/collect_pmc.py documents the
+    calibration).  Returns (bytes, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    pat = {"stats": "stats_", "chain": "chain_", "remap": "remap_", "ccc": "ccc_"}[kernel_class]
+    med = lambda v: sorted(v)[len(v) // 2] if v else None
+    total = 0.0
+    tmp = tempfile.mkdtemp(prefix="rip_pmc_", dir="/tmp")
+    try:
+        for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc",
+                   "--workload", args.workload, "--batch", str(args.batch)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=240, check=False)
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if pat in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not per:
+                return None, "rocprofv3 --pmc %s produced no rows (rc %d)" % (counter, r.returncode)
+            total += sum(med(v) for v in per.values()) * 1024.0 * factor  # one launch of every kernel of the class
+        return int(total), None
+    except Exception as e:  # noqa: BLE001 -- the bench line must come out whatever the profiler does
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def baseline_metric():
@@ -361,6 +402,14 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if world == 1 and not args.no_pmc:
+        live, why = live_pmc_traffic(args, dom)
+        if live is not None:
+            roofline["traffic"] = live
+            roofline["traffic_source"] = ("measured in this run: the same command re-run under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                                          "(separate passes, KiB, x2 on FETCH_SIZE for gfx950), median launch of the %s kernels" % dom)
+        elif roofline.get("traffic_source"):
+            roofline["traffic_source"] += "; live PMC pass unavailable (%s)" % why
     if world == 1 and not args.no_hbm_probe:
         # what this box's HBM actually delivers to a plain streaming kernel, beside the 8 TB/s spec
         del out

@@ -34,7 +34,7 @@ def main():
     for wl in workloads:
         for n in names:
             env = dict(os.environ, RIP_LIBRARY=os.path.join(VDIR, n + ".so"))
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-hbm-probe", "--workload", wl, "--steps", "10"],
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc", "--workload", wl, "--steps", "10"],
                                env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if not line:

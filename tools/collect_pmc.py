@@ -24,7 +24,7 @@ CLASS = {"stats": "stats_", "chain": "chain_", "remap": "remap_", "ccc": "ccc_"}
 def run_pass(out_dir, name, counters, workload):
     d = os.path.join(out_dir, "pmc_%s_%s" % (workload, name))
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--workload", workload]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc", "--workload", workload]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     rows = []

@@ -16,7 +16,7 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     d = os.path.join(out_dir, "pmc_%s_%s" % (wl, counters[0]))
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--workload", wl]
+           os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc", "--workload", wl]
     subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     per = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

@@ -30,7 +30,7 @@ def main():
     for wl in workloads:
         d = os.path.join(out_dir, "sq_%s" % wl)
         cmd = ["rocprofv3", "--pmc"] + SQ + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--workload", wl]
+               os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc", "--workload", wl]
         subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
         per = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

@@ -2,7 +2,7 @@
 # L2 hit / miss counters of the hot kernels (config2 bench).  usage (GPU box): l2_hit_probe.sh
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_READ_sum TCC_WRITE_sum --kernel-trace --output-format csv -d /tmp/l2 -o p -- \
-  python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-probe > /dev/null 2>&1
+  python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-hbm-probe --no-pmc > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, collections, re
 d = collections.defaultdict(lambda: collections.defaultdict(list))
