@@ -385,19 +385,49 @@ def main():
     if world > 1:
         # The only data movement between ranks on this path: the frame scatter when a batch originates on one rank.
         # Timed outside the steady state (it is bounded by the source GPU's xGMI egress) and reported apart.
-        sc_dev = "cuda" if backend == "nccl" else "cpu"  # gloo rehearsal: point-to-point needs host tensors
-        src_batch = (frames if backend == "nccl" else frames.cpu()) if rank == 0 else None
-        barrier()
-        t_sc = time.perf_counter()
-        mine = sharding.scatter_frames(src_batch, (height, width), device=sc_dev)
-        barrier()
-        t_sc = sharding.max_over_ranks(time.perf_counter() - t_sc)
-        a, b = sharding.frame_range_of_rank(args.batch, world, 1)
-        scatter = {"ranks": world, "backend": backend, "frames": args.batch, "frames_per_destination": b - a,
-                   "bytes_per_destination": (b - a) * height * width, "seconds": round(t_sc, 6),
-                   "GBps_per_destination": round((b - a) * height * width / t_sc / 1e9, 3),
-                   "GBps_source_egress": round((args.batch - (b - a)) * height * width / t_sc / 1e9, 3)}
-        del mine
+        # It runs LAST and under a watchdog: the steady-state numbers above are complete at this point, so a point-to-point
+        # transfer that does not come back within 90 s must not cost the run its line -- every rank then leaves on its own,
+        # rank 0 after printing the line with the scatter marked as timed out.
+        import threading
+        state = {"done": False}
+
+        def bail_out():
+            if state["done"]:
+                return
+            if rank == 0:
+                print(json.dumps(dict(result_base(), scatter={"ranks": world, "backend": backend, "error": "scatter did not complete within 90 s"})),
+                      flush=True)
+            os._exit(0)
+
+        def result_base():
+            return {"metric": baseline_metric(), "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                    "config": {"workload": "%dx%d %s, %s" % (width, height, pattern, stages), "frames_per_step_per_gpu": args.batch,
+                               "sharding": "one camera stream per GPU, no data-path collective", "name": args.workload},
+                    "roofline": roofline}
+
+        timer = threading.Timer(90.0, bail_out)
+        timer.daemon = True
+        timer.start()
+        try:
+            sc_dev = "cuda" if backend == "nccl" else "cpu"  # gloo rehearsal: point-to-point needs host tensors
+            src_batch = (frames if backend == "nccl" else frames.cpu()) if rank == 0 else None
+            barrier()
+            t_sc = time.perf_counter()
+            mine = sharding.scatter_frames(src_batch, (height, width), device=sc_dev)
+            barrier()
+            t_sc = sharding.max_over_ranks(time.perf_counter() - t_sc)
+            a, b = sharding.frame_range_of_rank(args.batch, world, 1)
+            scatter = {"ranks": world, "backend": backend, "frames": args.batch, "frames_per_destination": b - a,
+                       "bytes_per_destination": (b - a) * height * width, "seconds": round(t_sc, 6),
+                       "GBps_per_destination": round((b - a) * height * width / t_sc / 1e9, 3),
+                       "GBps_source_egress": round((args.batch - (b - a)) * height * width / t_sc / 1e9, 3)}
+            del mine
+        except Exception as e:  # noqa: BLE001 -- report, never lose the line
+            scatter = {"ranks": world, "backend": backend, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        state["done"] = True
+        timer.cancel()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
