@@ -87,27 +87,26 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
   }
 }
 
-// Grey-world statistics of four planar pixels, two pixels per instruction: the bytes are widened to
-// 16-bit lanes; max/min with v_pk_max/min_u16; both sides of the saturation test
-// (max - min) * 255 > thresh255 * max fit 16 bits (thresh255 <= 255 after the clamp below, which does
-// not change the outcome: for thresh255 >= 255 no pixel is ever skipped); the masked channel sums are
-// one v_dot2_u32_u16 per channel with the 0/1 keep flags as weights.
+// Grey-world statistics of four planar pixels, two pixels per instruction: the bytes are widened to 16-bit lanes;
+// max/min with v_pk_max/min_u16.  GrayworldWB skips a pixel iff (max - min) * 255 > thresh255 * max, i.e. keeps it iff
+// (255 - thresh255) * max < 255 * min + 1: both sides fit 16 bits (thresh255 <= 255 after the clamp below, which does not change
+// the outcome: for thresh255 >= 255 no pixel is ever skipped), so the 0/1 keep flag is min(sat_sub(255 * min + 1, s * max), 1) --
+// one packed multiply-add, one packed multiply, one saturating subtract, one min -- and the masked channel sums are one
+// v_dot2_u32_u16 per channel with the flags as weights.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ void grayworld_add_swar(const Planar& v, unsigned thresh255, StatAcc& a) {
   constexpr uint32_t M8 = 0x00FF00FFu;
-  const u16x2 t2 = as_u16x2(thresh255 * 0x00010001u), one2 = as_u16x2(0x00010001u);
+  const u16x2 s2 = as_u16x2((255u - thresh255) * 0x00010001u), one2 = as_u16x2(0x00010001u), c255 = as_u16x2(0x00FF00FFu);
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     const uint32_t bw = (half ? v.b >> 8 : v.b) & M8, gw = (half ? v.g >> 8 : v.g) & M8, rw = (half ? v.r >> 8 : v.r) & M8;
     const u16x2 b2 = as_u16x2(bw), g2 = as_u16x2(gw), r2 = as_u16x2(rw);
     const u16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(b2, g2), r2);
     const u16x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(b2, g2), r2);
-    const uint32_t d = __builtin_bit_cast(uint32_t, mx) - __builtin_bit_cast(uint32_t, mn);  // lane-wise: max >= min
-    const u16x2 lhs = as_u16x2((d << 8) - d);                                                // * 255, <= 65025 per lane
-    const u16x2 rhs = mx * t2;
-    const u16x2 skip = __builtin_elementwise_min(__builtin_elementwise_sub_sat(lhs, rhs), one2);  // 1 where lhs > rhs
-    const u16x2 keep = one2 - skip;
+    const u16x2 lhs = mn * c255 + one2;  // 255 * min + 1 <= 65026
+    const u16x2 rhs = mx * s2;           // (255 - thresh255) * max <= 65025
+    const u16x2 keep = __builtin_elementwise_min(__builtin_elementwise_sub_sat(lhs, rhs), one2);  // 1 where lhs > rhs
     a.s[0] = __builtin_amdgcn_udot2(b2, keep, a.s[0], false);
     a.s[1] = __builtin_amdgcn_udot2(g2, keep, a.s[1], false);
     a.s[2] = __builtin_amdgcn_udot2(r2, keep, a.s[2], false);
@@ -166,21 +165,23 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, int c
                    (int)((rowpx[ly].r >> (8 * lx)) & 0xFFu), a, s_hist);
       }
     };
-    // two row pairs per iteration so the carried rows change roles without register moves; the two
-    // rows of the next pair are in flight while the current pair is reduced
+    // two row pairs per iteration so the carried rows change roles without register moves; the rows of the NEXT TWO
+    // pairs are in flight while the current pair is reduced (one pair ahead left every wave waiting on HBM once per
+    // pair: the reduction of a pair is ~400 issue cycles, the load latency under load several times that)
     int y0 = pair_begin * 2;
     RowPrep ra = prep(fetch_row(y0 - 1)), rb = prep(fetch_row(y0));
     RawRow n0 = fetch_row(y0 + 1), n1 = fetch_row(y0 + 2);
+    RawRow m0 = fetch_row(y0 + 3), m1 = fetch_row(y0 + 4);
     for (int pair = pair_begin; pair < pair_end; pair += 2, y0 += 4) {
       const RowPrep rc = prep(n0), rd = prep(n1);
-      n0 = fetch_row(y0 + 3);
-      n1 = fetch_row(y0 + 4);
-      consume(ra, rb, rc, rd, y0);
-      if (pair + 1 >= pair_end) break;
-      ra = prep(n0);
-      rb = prep(n1);
       n0 = fetch_row(y0 + 5);
       n1 = fetch_row(y0 + 6);
+      consume(ra, rb, rc, rd, y0);
+      if (pair + 1 >= pair_end) break;
+      ra = prep(m0);
+      rb = prep(m1);
+      m0 = fetch_row(y0 + 7);
+      m1 = fetch_row(y0 + 8);
       consume(rc, rd, ra, rb, y0 + 2);
     }
   }
