@@ -18,5 +18,6 @@ python "$ROOT/bench.py" 2>/dev/null | tail -1 > "$OUT/bench_default.json"
 python "$ROOT/tools/collect_pmc_sq.py" "$OUT/sq" config2 chain config3 config5 > "$OUT/sq.log" 2>&1
 "$ROOT/tools/probes/bin/valu_probe2" > "$OUT/valu_probe2.txt" 2>&1
 "$ROOT/tools/probes/bin/valu_probe3" > "$OUT/valu_probe3.txt" 2>&1
+cp "$OUT/sq/pmc_sq_summary.txt" "$OUT/pmc_sq_summary.txt"
 rm -rf "$OUT/kt" "$OUT"/pmc/pmc_*_fetch "$OUT"/pmc/pmc_*_write "$OUT"/sq/sq_*
 ls -la "$OUT" "$OUT/pmc"
