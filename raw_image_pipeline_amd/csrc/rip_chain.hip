@@ -172,7 +172,7 @@ __device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& 
   }
   if constexpr ((BITS & ST_HSV) != 0) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) apply_hsv(hr.g, tb, q[k][0], q[k][1], q[k][2]);
+    for (int k = 0; k < 4; k++) apply_hsv(hr.g, tb, q[k][0], q[k][1], q[k][2], hr.unit);
   }
 }
 
@@ -239,6 +239,14 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
       const __amdgpu_buffer_rsrc_t tap = frame_rsrc(has_tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr, has_tap ? tap_bytes : 0u);
       FrameWb w;
       if (WB != WB_NONE) w = p.wb[frame];
+      if constexpr (WB == WB_FLOAT || WB == WB_SIMPLE || WB == WB_PCA) {
+        // the per-frame float gains arrive through scalar loads; as SGPR operands they would make every multiply of the
+        // white balance issue at 4.3 cycles instead of 2.45 (once per frame: a handful of v_mov)
+#pragma unroll
+        for (int c = 0; c < 3; c++) asm volatile("" : "+v"(w.fg[c]));
+#pragma unroll
+        for (int c = 0; c < 4; c++) asm volatile("" : "+v"(w.pca[c]));
+      }
       Window win;
       load_window(src, wo, win);
       Planar rowpx[2];
