@@ -2,6 +2,7 @@
 // model, arg-max (convolutional_color_constancy.cpp:91-340).
 // Shared device code and the stage-by-stage reference citations: rip_device.hpp.
 #include "rip_device.hpp"
+#include <atomic>
 
 namespace rip {
 namespace {
@@ -411,9 +412,14 @@ void launch_ccc_estimate(const CccParams& p, hipStream_t stream) {
   const int lds_min = tune_int("RIP_CCC_LDS_HIST_MIN", 48);
   if (p.n_frames >= lds_min) {
     constexpr unsigned lds = kHistWords * sizeof(unsigned) + sizeof(CccSampleTabs);
-    static const bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(ccc_hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)lds) == hipSuccess);
-    (void)attr;
+    // the opt-in above 64 KB of dynamic LDS is per device: a process that drives several GPUs (CameraRig) needs it on each
+    static std::atomic<unsigned long long> opted_in{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(opted_in.load(std::memory_order_relaxed) & bit) &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ccc_hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+      opted_in.fetch_or(bit, std::memory_order_relaxed);
     hipLaunchKernelGGL(ccc_hist_lds_kernel, dim3(p.n_frames), dim3(kHistLdsThreads), lds, stream, p);
   } else {
     (void)hipMemsetAsync(p.hist_counts, 0, (size_t)p.n_frames * 65536 * sizeof(unsigned), stream);
