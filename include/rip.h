@@ -129,7 +129,13 @@ rip_status rip_set_ccc_kalman_model(rip_pipeline* p, double h, double r);
 /* ---- other interfaces (hpp:59-61) -------------------------------------------------------- */
 rip_status rip_reset_white_balance_temporal_consistency(rip_pipeline* p); /* cpp:218-220 */
 rip_status rip_set_gpu(rip_pipeline* p, int use_gpu);                     /* cpp:210-212; recorded only */
-rip_status rip_set_debug(rip_pipeline* p, int debug);                     /* cpp:214-216; recorded only */
+/* cpp:214-216.  While on, every rip_apply() of an 8-bit frame also writes the image after each of the eight modules --
+ * enabled or not -- as the reference's pipeline() does (raw_image_pipeline.hpp:143-172 -> saveDebugImage :179-186: copy,
+ * cv::normalize(0, 255, NORM_MINMAX), cv::imwrite): /tmp/00_debayer.png, 01_flip, 02_white_balancing, 03_color_calibration,
+ * 04_gamma_correction, 05_vignetting_correction, 06_color_enhancer, 07_undistortion (.png).  The environment variable
+ * RIP_DEBUG_DIR replaces /tmp.  The fused kernel is re-run once per module prefix with the gains of the real pass; the
+ * PNGs hold the same pixels as the reference's (stored, not compressed).  rip_apply_device() never dumps. */
+rip_status rip_set_debug(rip_pipeline* p, int debug);
 
 /* ---- setters (hpp:66-104; cpp:241-383) ---------------------------------------------------- */
 rip_status rip_set_debayer(rip_pipeline* p, int enabled);                         /* hpp:66 */
@@ -225,6 +231,10 @@ rip_status rip_get_vignetting_mask(rip_pipeline* p, int rows, int cols, float* o
 /* Test hook: the double-double atan the device map builder uses (rip_maps.hip), evaluated on the device for n doubles;
  * the parity tests compare it with libm's over the range fisheye maps reach. */
 rip_status rip_debug_atan(rip_pipeline* p, const double* in, double* out, int n);
+/* Test hook for the debug dumps: writes image (rows x cols x channels bytes, channels 1 or 3 = BGR) to path as the PNG
+ * writer of rip_set_debug does, after the reference's min-max normalisation when normalize != 0.  No device needed;
+ * p may be NULL. */
+rip_status rip_debug_write_png(rip_pipeline* p, const char* path, const uint8_t* image, int rows, int cols, int channels, int normalize);
 const char* rip_version(void);
 
 #ifdef __cplusplus

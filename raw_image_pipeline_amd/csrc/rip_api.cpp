@@ -154,7 +154,7 @@ struct rip_pipeline {
   std::vector<int> prof_ids;
   size_t prof_used = 0;
   // host-apply staging and last-frame taps
-  DevBuf d_in, d_out, d_tap_deb, d_tap_col;
+  DevBuf d_in, d_out, d_tap_deb, d_tap_col, d_dbg;
   int last_rows[3] = {0, 0, 0}, last_cols[3] = {0, 0, 0}, last_cn[3] = {0, 0, 0};
   bool last_valid[3] = {false, false, false};
   DevBuf* last_buf[3] = {nullptr, nullptr, nullptr};
@@ -165,7 +165,7 @@ struct rip_pipeline {
     for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
     for (DevBuf* b : {&d_tabs, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
                       &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col, &d_vig, &d_plan_words,
-                      &d_plan_tiles, &d_plan_border})
+                      &d_plan_tiles, &d_plan_border, &d_dbg})
       b->release();
   }
 };
@@ -501,8 +501,11 @@ Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const st
 }
 
 // Enqueues the whole chain for n frames.  d_out rows of out_step bytes.  Taps may be null.
+// reuse_wb: the white-balance gains of the previous launch (same frames) are applied again and no estimator runs -- the
+// debug stage dumps re-run prefixes of the chain without advancing the ccc Kalman state.
 void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_step, size_t in_frame_stride, int n, int rows,
-               int cols, uint8_t* d_out, size_t out_step, size_t out_frame_stride, uint8_t* d_tap_deb, uint8_t* d_tap_col) {
+               int cols, uint8_t* d_out, size_t out_step, size_t out_frame_stride, uint8_t* d_tap_deb, uint8_t* d_tap_col,
+               bool reuse_wb = false) {
   DeviceGuard device_guard(p->device);
   if (pl.elem_bytes == 2) {  // 16-bit Bayer extension: one kernel, no taps
     rip::Debayer16Params d = {};
@@ -538,7 +541,9 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
 
   p->d_wb.reserve(sizeof(rip::FrameWb) * (size_t)n);
   // ---- white-balance statistics ---------------------------------------------------------------
-  if (pl.wb_mode == rip::WB_Q8 || pl.wb_mode == rip::WB_PCA || pl.wb_mode == rip::WB_SIMPLE) {
+  if (reuse_wb) {
+    if (p->last_batch_frames != n) throw DeviceError("internal: white-balance gains of another batch");
+  } else if (pl.wb_mode == rip::WB_Q8 || pl.wb_mode == rip::WB_PCA || pl.wb_mode == rip::WB_SIMPLE) {
     p->d_stats.reserve(sizeof(rip::FrameStats) * (size_t)n);
     HIP_CHECK(hipMemsetAsync(p->d_stats.ptr, 0, sizeof(rip::FrameStats) * (size_t)n, p->stream));
     if (pl.wb_mode == rip::WB_SIMPLE) {
@@ -711,6 +716,48 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) throw DeviceError(std::string("kernel launch failed: ") + hipGetErrorString(le));
+}
+
+// setDebug(true): raw_image_pipeline.hpp:143-172 writes the image after EVERY module -- enabled or not -- to
+// /tmp/0N_<module>.png through saveDebugImage (:179-186: copy, cv::normalize(0, 255, NORM_MINMAX), cv::imwrite).  The modules
+// are one fused kernel here, so the image after module k is produced by running the chain once more with the modules after k
+// switched off (same input frame still in d_in, same white-balance gains: reuse_wb).  RIP_DEBUG_DIR replaces /tmp.
+void write_debug_dumps(rip_pipeline* p, const Plan& pl, size_t in_pitch, size_t in_bytes, int rows, int cols, const uint8_t* final_image) {
+  static const char* const kNames[8] = {"00_debayer", "01_flip", "02_white_balancing", "03_color_calibration", "04_gamma_correction",
+                                        "05_vignetting_correction", "06_color_enhancer", "07_undistortion"};
+  static const int kStages[8] = {0, 0, 0, rip::ST_CC, rip::ST_CC | rip::ST_GAMMA, rip::ST_CC | rip::ST_GAMMA | rip::ST_VIG,
+                                 rip::ST_CC | rip::ST_GAMMA | rip::ST_VIG | rip::ST_HSV, rip::ST_CC | rip::ST_GAMMA | rip::ST_VIG | rip::ST_HSV};
+  const char* dir_env = std::getenv("RIP_DEBUG_DIR");
+  const std::string dir = dir_env && *dir_env ? dir_env : "/tmp";
+  std::vector<uint8_t> host;
+  for (int k = 0; k < 8; k++) {
+    int r, c;
+    if (k == 7) {  // after the undistortion module: the output of this call
+      r = pl.out_rows;
+      c = pl.out_cols;
+      host.assign(final_image, final_image + (size_t)r * c * pl.channels);
+    } else {
+      Plan s = pl;
+      s.remap = false;
+      if (k < 1) s.flip_angle = 0;
+      const bool swap = s.flip_angle == 90 || s.flip_angle == 270;
+      s.mid_rows = swap ? cols : rows;
+      s.mid_cols = swap ? rows : cols;
+      if (k < 2) s.wb_mode = rip::WB_NONE;
+      s.stage_bits &= kStages[k];
+      s.out_rows = r = s.mid_rows;
+      s.out_cols = c = s.mid_cols;
+      const size_t bytes = (size_t)r * c * s.channels;
+      p->d_dbg.reserve(bytes);
+      run_batch(p, s, p->d_in.as<uint8_t>(), in_pitch, in_bytes, 1, rows, cols, p->d_dbg.as<uint8_t>(), 0, 0, nullptr, nullptr, true);
+      host.resize(bytes);
+      HIP_CHECK(hipMemcpyAsync(host.data(), p->d_dbg.ptr, bytes, hipMemcpyDeviceToHost, p->stream));
+      HIP_CHECK(hipStreamSynchronize(p->stream));
+    }
+    rip::normalize_minmax_u8(host.data(), host.size());
+    const std::string path = dir + "/" + kNames[k] + ".png";
+    if (!rip::write_png(path, host.data(), r, c, pl.channels)) std::fprintf(stderr, "raw_image_pipeline: could not write %s\n", path.c_str());
+  }
 }
 
 template <typename F>
@@ -937,6 +984,7 @@ rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, 
     run_batch(p, pl, p->d_in.as<uint8_t>(), in_pitch, in_bytes, 1, rows, cols, p->d_out.as<uint8_t>(), 0, 0, tap_deb, tap_col);
     HIP_CHECK(hipMemcpyAsync(out, p->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, p->stream));
     HIP_CHECK(hipStreamSynchronize(p->stream));
+    if (p->m.debug && eb == 1) write_debug_dumps(p, pl, in_pitch, in_bytes, rows, cols, out);
     for (int i = 0; i < 3; i++) p->last_valid[i] = false;
     auto remember = [&](int which, DevBuf* buf, int r, int c, bool on) {
       p->last_valid[which] = on;
@@ -1258,6 +1306,16 @@ rip_status rip_profile_end(rip_pipeline* p, double ms_sum[RIP_KERNEL_COUNT], int
     p->prof_on = false;
     p->prof_used = 0;
     p->prof_ids.clear();
+  });
+}
+
+rip_status rip_debug_write_png(rip_pipeline* p, const char* path, const uint8_t* image, int rows, int cols, int channels, int normalize) {
+  return guarded(p, [&] {
+    if (!path || !image) throw InvalidArgument("null path or image");
+    if (rows < 1 || cols < 1 || (channels != 1 && channels != 3)) throw InvalidArgument("PNG dumps hold 1- or 3-channel 8-bit images");
+    std::vector<uint8_t> tmp(image, image + (size_t)rows * cols * channels);
+    if (normalize) rip::normalize_minmax_u8(tmp.data(), tmp.size());
+    if (!rip::write_png(path, tmp.data(), rows, cols, channels)) throw rip::YamlError(std::string("cannot write ") + path);
   });
 }
 

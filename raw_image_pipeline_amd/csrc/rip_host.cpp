@@ -928,4 +928,124 @@ void ccc_build_scalar_tables(float log_tab[256], std::vector<float>& accum_tab, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Debug stage dumps
+// ---------------------------------------------------------------------------------------------
+void normalize_minmax_u8(uint8_t* data, size_t n) {
+  if (n == 0) return;
+  int lo = 255, hi = 0;
+  for (size_t i = 0; i < n; i++) {
+    lo = std::min(lo, (int)data[i]);
+    hi = std::max(hi, (int)data[i]);
+  }
+  const double smin = lo, smax = hi;
+  const double scale = 255.0 * (smax - smin > 2.220446049250313e-16 ? 1.0 / (smax - smin) : 0.0);
+  const double shift = 0.0 - smin * scale;
+  const float a = (float)scale, b = (float)shift;
+  uint8_t lut[256];
+  for (int v = 0; v < 256; v++) {
+    const float r = (float)v * a + b;  // multiply, then add (the build runs with -ffp-contract=off)
+    long q = std::lrintf(r);
+    lut[v] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+  }
+  for (size_t i = 0; i < n; i++) data[i] = lut[data[i]];
+}
+
+namespace {
+struct Crc32 {
+  uint32_t table[256];
+  Crc32() {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+  }
+  uint32_t update(uint32_t crc, const uint8_t* p, size_t n) const {
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return crc;
+  }
+};
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+  for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s));
+}
+bool write_chunk(std::FILE* f, const Crc32& crc, const char type[4], const std::vector<uint8_t>& body) {
+  std::vector<uint8_t> head;
+  put_be32(head, (uint32_t)body.size());
+  head.insert(head.end(), type, type + 4);
+  uint32_t c = crc.update(0xFFFFFFFFu, head.data() + 4, 4);
+  c = crc.update(c, body.data(), body.size()) ^ 0xFFFFFFFFu;
+  std::vector<uint8_t> tail;
+  put_be32(tail, c);
+  return std::fwrite(head.data(), 1, head.size(), f) == head.size() &&
+         (body.empty() || std::fwrite(body.data(), 1, body.size(), f) == body.size()) && std::fwrite(tail.data(), 1, 4, f) == 4;
+}
+}  // namespace
+
+bool write_png(const std::string& path, const uint8_t* data, int rows, int cols, int channels) {
+  if (!data || rows < 1 || cols < 1 || (channels != 1 && channels != 3)) return false;
+  static const Crc32 crc;
+  // raw scanlines: filter byte 0 + pixels (RGB order)
+  const size_t row_bytes = (size_t)cols * channels + 1;
+  std::vector<uint8_t> raw(row_bytes * rows);
+  for (int y = 0; y < rows; y++) {
+    uint8_t* d = raw.data() + row_bytes * y;
+    const uint8_t* s = data + (size_t)y * cols * channels;
+    *d++ = 0;
+    if (channels == 1) {
+      std::memcpy(d, s, (size_t)cols);
+    } else {
+      for (int x = 0; x < cols; x++) {
+        d[3 * x] = s[3 * x + 2];
+        d[3 * x + 1] = s[3 * x + 1];
+        d[3 * x + 2] = s[3 * x];
+      }
+    }
+  }
+  // zlib stream of stored deflate blocks
+  std::vector<uint8_t> z;
+  z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+  z.push_back(0x78);
+  z.push_back(0x01);
+  uint32_t s1 = 1, s2 = 0;
+  size_t pos = 0;
+  while (pos < raw.size()) {
+    const size_t len = std::min<size_t>(65535, raw.size() - pos);
+    z.push_back(pos + len == raw.size() ? 1 : 0);
+    z.push_back((uint8_t)(len & 0xFF));
+    z.push_back((uint8_t)(len >> 8));
+    z.push_back((uint8_t)(~len & 0xFF));
+    z.push_back((uint8_t)((~len >> 8) & 0xFF));
+    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + len);
+    for (size_t i = 0; i < len;) {  // adler32, 5552 bytes between reductions
+      const size_t run = std::min<size_t>(5552, len - i);
+      for (size_t k = 0; k < run; k++) {
+        s1 += raw[pos + i + k];
+        s2 += s1;
+      }
+      s1 %= 65521u;
+      s2 %= 65521u;
+      i += run;
+    }
+    pos += len;
+  }
+  put_be32(z, (s2 << 16) | s1);
+  std::FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) return false;
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+  std::vector<uint8_t> ihdr;
+  put_be32(ihdr, (uint32_t)cols);
+  put_be32(ihdr, (uint32_t)rows);
+  ihdr.push_back(8);                              // bit depth
+  ihdr.push_back(channels == 3 ? 2 : 0);          // colour type: truecolour / greyscale
+  ihdr.push_back(0);
+  ihdr.push_back(0);
+  ihdr.push_back(0);
+  bool ok = std::fwrite(sig, 1, 8, f) == 8 && write_chunk(f, crc, "IHDR", ihdr) && write_chunk(f, crc, "IDAT", z) &&
+            write_chunk(f, crc, "IEND", {});
+  ok = (std::fclose(f) == 0) && ok;
+  return ok;
+}
+
+
 }  // namespace rip

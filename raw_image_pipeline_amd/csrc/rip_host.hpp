@@ -117,6 +117,17 @@ const ColorTables& color_tables();  // built once
 void build_vignette_mask(int rows, int cols, double scale, double a2, double a4, std::vector<float>& mask);
 
 // ---------------------------------------------------------------------------------------------
+// Debug stage dumps (raw_image_pipeline.hpp:179-186 saveDebugImage): cv::normalize(NORM_MINMAX, 0..255) over all
+// channels of the 8-bit image, then cv::imwrite to a .png
+// ---------------------------------------------------------------------------------------------
+// scale = 255 / (max - min) (0 when max == min), shift = -min * scale in double; per byte
+// saturate_cast<uchar>(v * (float)scale + (float)shift), float multiply then add, round half to even (convertTo 8U -> 8U)
+void normalize_minmax_u8(uint8_t* data, size_t n);
+// 8-bit PNG, grey (channels 1) or colour (channels 3, BGR in memory -> RGB in the file, as cv::imwrite does); the zlib
+// stream uses stored blocks (no compression: a debugging aid, not an encoder).  false when the file cannot be written.
+bool write_png(const std::string& path, const uint8_t* data, int rows, int cols, int channels);
+
+// ---------------------------------------------------------------------------------------------
 // Fisheye undistortion (undistortion.cpp:197-238 -> OpenCV 4.2 calib3d/fisheye.cpp), double
 // ---------------------------------------------------------------------------------------------
 void fisheye_estimate_new_camera_matrix(const double K[9], const double D[4], int w, int h, const double R[9],

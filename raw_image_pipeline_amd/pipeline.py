@@ -276,7 +276,20 @@ class RawImagePipeline:
         self._call("rip_set_gpu", int(bool(use_gpu)))
 
     def set_debug(self, debug):
+        """While on, process()/apply() of an 8-bit frame also write the image after each of the eight modules to
+        /tmp/0N_<module>.png (RIP_DEBUG_DIR replaces /tmp), min-max normalised like the reference's saveDebugImage
+        (raw_image_pipeline.hpp:143-186)."""
         self._call("rip_set_debug", int(bool(debug)))
+
+    DEBUG_DUMP_NAMES = ("00_debayer", "01_flip", "02_white_balancing", "03_color_calibration", "04_gamma_correction",
+                        "05_vignetting_correction", "06_color_enhancer", "07_undistortion")
+
+    def debug_write_png(self, path, image, normalize=True):
+        """Test hook: the PNG writer (and min-max normalisation) of the debug dumps on a host image (H x W or H x W x 3 BGR)."""
+        a = np.ascontiguousarray(image, np.uint8)
+        cn = 1 if a.ndim == 2 else a.shape[2]
+        self._check(self._lib.rip_debug_write_png(self._h, str(path).encode(), a.ctypes.data_as(C.c_void_p), int(a.shape[0]),
+                                                  int(a.shape[1]), int(cn), int(bool(normalize))))
 
     # ---- setters (names as in raw_image_pipeline_python.cpp:25-58) --------------------------------
     def set_debayer(self, enabled):

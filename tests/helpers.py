@@ -97,3 +97,67 @@ def assert_images_equal(got, ref, what="", tol=0):
     assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)
     d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
     assert d.max() <= tol, "%s: max |diff| = %d on %d of %d values" % (what, d.max(), int((d > tol).sum()), d.size)
+
+
+# ---- debug stage dumps (raw_image_pipeline.hpp:143-186) ---------------------------------------------
+DUMP_NAMES = ("00_debayer", "01_flip", "02_white_balancing", "03_color_calibration", "04_gamma_correction",
+              "05_vignetting_correction", "06_color_enhancer", "07_undistortion")
+# configuration keys of the modules that run AFTER dump k was taken
+_LATER = (("flip", "wb", "cc", "gamma", "vig", "ce", "undistort"), ("wb", "cc", "gamma", "vig", "ce", "undistort"),
+          ("cc", "gamma", "vig", "ce", "undistort"), ("gamma", "vig", "ce", "undistort"), ("vig", "ce", "undistort"),
+          ("ce", "undistort"), ("undistort",), ())
+
+
+def prefix_cfg(c, k):
+    """The configuration whose output is the image after module k of configuration c."""
+    s = dict(c)
+    for key in _LATER[k]:
+        s[key] = False
+    return s
+
+
+def normalize_minmax(img):
+    """cv::normalize(src, dst, 0, 255, NORM_MINMAX) for 8-bit data, restated: scale and shift in double, applied in float
+    (multiply, then add), rounded half to even, saturated."""
+    a = np.asarray(img, np.uint8)
+    smin, smax = float(a.min()), float(a.max())
+    scale = 255.0 * (1.0 / (smax - smin) if smax - smin > np.finfo(np.float64).eps else 0.0)
+    shift = 0.0 - smin * scale
+    r = a.astype(np.float32) * np.float32(scale)
+    r = r + np.float32(shift)
+    return np.clip(np.rint(r), 0, 255).astype(np.uint8)
+
+
+def read_png(path):
+    """8-bit grey / RGB PNG -> H x W or H x W x 3 **BGR** array.  Pillow decodes when it is installed (an independent
+    decoder: it checks the chunk CRCs and the zlib stream); otherwise a minimal reader for non-interlaced files."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            im.load()
+            a = np.asarray(im)
+        assert a.dtype == np.uint8
+        return a if a.ndim == 2 else a[:, :, ::-1].copy()
+    except ImportError:
+        pass
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(typ + body) & 0xFFFFFFFF)
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h, depth, ctype, _, _, interlace = hdr
+    assert depth == 8 and ctype in (0, 2) and interlace == 0
+    cn = 3 if ctype == 2 else 1
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * cn + 1)
+    assert not rows[:, 0].any(), "only filter type 0 is handled"
+    a = rows[:, 1:].reshape(h, w, cn)
+    return a[:, :, 0].copy() if cn == 1 else a[:, :, ::-1].copy()

@@ -257,3 +257,31 @@ def test_16bit_bayer_extension_is_opt_in(host_pipe):
     with pytest.raises(Exception, match="8-bit stages"):
         p.query_output(48, 64, 1, "bayer_rggb16")
     assert p.query_output(48, 64, 1, "bayer_rggb8") == (64, 48, 3, "bgr8")  # 8-bit frames are unaffected
+
+
+def test_debug_dump_normalisation_and_png_writer(host_pipe, tmp_path):
+    """saveDebugImage (raw_image_pipeline.hpp:179-186): cv::normalize(0, 255, NORM_MINMAX) over all channels, then a PNG that
+    a standard decoder reads back (RGB order in the file, BGR in memory)."""
+    from helpers import normalize_minmax, read_png
+    rng = np.random.default_rng(11)
+    bgr = rng.integers(17, 204, (37, 53, 3), dtype=np.uint8)
+    bgr[0, 0] = (17, 99, 203)  # both extremes present
+    path = str(tmp_path / "dump.png")
+    host_pipe.debug_write_png(path, bgr, normalize=False)
+    assert np.array_equal(read_png(path), bgr)
+    host_pipe.debug_write_png(path, bgr, normalize=True)
+    got = read_png(path)
+    assert np.array_equal(got, normalize_minmax(bgr)) and got.min() == 0 and got.max() == 255
+    # known answers: 17 -> 0, 203 -> 255, 110 -> round(93 * (255 / 186)) = round(127.5) -> half to even = 128
+    lut = normalize_minmax(np.array([[17, 110, 203]], np.uint8))
+    assert lut.tolist() == [[0, 128, 255]]
+    # a flat image has no range: scale 0, everything becomes 0
+    flat = np.full((9, 5), 77, np.uint8)
+    host_pipe.debug_write_png(path, flat, normalize=True)
+    assert np.array_equal(read_png(path), np.zeros_like(flat))
+    # grey, more than one stored deflate block (> 65535 bytes) and a row length that is not a multiple of anything
+    grey = rng.integers(0, 256, (301, 333), dtype=np.uint8)
+    host_pipe.debug_write_png(path, grey, normalize=False)
+    assert np.array_equal(read_png(path), grey)
+    with pytest.raises(RipIOError):
+        host_pipe.debug_write_png(str(tmp_path / "no_such_dir" / "x.png"), grey)

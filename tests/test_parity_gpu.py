@@ -539,3 +539,74 @@ def test_error_behaviour(gpu_pipe):
     configure(gpu_pipe, cfg(wb=True, wb_method="grey_world", cc=True, ce=True))
     out = gpu_pipe.process(frame, "mono8")  # 3-channel-only stages are skipped silently
     assert np.array_equal(out, frame)
+
+
+# ---- debug stage dumps (setDebug, raw_image_pipeline.hpp:143-186) ------------------------------------
+@pytest.mark.parametrize("flip_angle", [180, 90])
+def test_debug_stage_dumps_full_chain(rip_lib, oracle, monkeypatch, tmp_path, flip_angle):
+    """With setDebug(true) every apply() leaves /tmp/0N_<module>.png (here RIP_DEBUG_DIR): the image after each of the eight
+    modules, min-max normalised.  Each must equal the normalised oracle output of the chain cut after that module; the
+    returned image is unaffected."""
+    from raw_image_pipeline_amd import RawImagePipeline
+    from helpers import DUMP_NAMES, normalize_minmax, prefix_cfg, read_png
+    monkeypatch.setenv("RIP_DEBUG_DIR", str(tmp_path))
+    w, h = 320, 240
+    cam = synth.camera_model(h, w) if flip_angle == 90 else synth.camera_model(w, h)  # the remap sees the rotated image
+    c = full_chain_cfg(w, h, flip_angle=flip_angle, ce=True, ce_sat=1.2, cam=cam)
+    pipe = RawImagePipeline(False, device=0)
+    configure(pipe, c)
+    frame = synth.gen_frame(w, h, "bayer_grbg8", seed=77, kind="scene")
+    pipe.set_debug(True)
+    got = pipe.process(frame, "bayer_grbg8")
+    ref, _ = oracle_run(oracle, c, frame, "bayer_grbg8")
+    assert_images_equal(got, ref, "final image with debug on")
+    for k, name in enumerate(DUMP_NAMES):
+        want, _ = oracle_run(oracle, prefix_cfg(c, k), frame, "bayer_grbg8")
+        assert_images_equal(read_png(str(tmp_path / (name + ".png"))), normalize_minmax(want), "dump %s" % name)
+    # debug off again: nothing is written
+    for name in DUMP_NAMES:
+        (tmp_path / (name + ".png")).unlink()
+    pipe.set_debug(False)
+    pipe.process(frame, "bayer_grbg8")
+    assert not list(tmp_path.iterdir())
+
+
+def test_debug_stage_dumps_do_not_advance_the_ccc_filter_and_handle_mono(rip_lib, oracle, monkeypatch, tmp_path):
+    """The dumps re-run prefixes of the chain with the gains of the real pass: a ccc stream with temporal consistency gives the
+    same frames with debug on as the oracle's single pass per frame (no extra Kalman updates), and dump 02 shows those gains.
+    A mono8 frame (only the gamma LUT applies) is dumped as grey PNGs."""
+    from raw_image_pipeline_amd import RawImagePipeline
+    from helpers import DUMP_NAMES, normalize_minmax, prefix_cfg, read_png
+    monkeypatch.setenv("RIP_DEBUG_DIR", str(tmp_path))
+    w, h, n = 384, 240, 4
+    filt, bias = synth.ccc_model()
+    pipe = RawImagePipeline(False, device=0)
+    pipe.set_ccc_model(filt, bias)
+    pipe.set_ccc_kalman_model(1.0, 10.0)
+    occ = oracle.CCC(filt, bias)
+    occ.set_kalman_model(1.0, 10.0)
+    c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=True, gamma=True, gamma_k=0.9)
+    configure(pipe, c)
+    pipe.reset_white_balance_temporal_consistency()
+    pipe.set_debug(True)
+    for i in range(n):
+        frame = synth.gen_frame(w, h, "bayer_gbrg8", seed=4100 + i, kind="scene", tint=(0.70 + 0.04 * i, 1.0, 0.55))
+        got = pipe.process(frame, "bayer_gbrg8")
+        ref, _ = oracle_run(oracle, c, frame, "bayer_gbrg8", ccc=occ)
+        assert_images_equal(got, ref, "ccc frame %d with debug on" % i, TOL_DECLARED)
+        # dump 07 is the final image, dump 04 too (nothing enabled after gamma), 01 == 00 (flip disabled)
+        assert np.array_equal(read_png(str(tmp_path / "07_undistortion.png")), normalize_minmax(got))
+        assert np.array_equal(read_png(str(tmp_path / "04_gamma_correction.png")), normalize_minmax(got))
+        assert np.array_equal(read_png(str(tmp_path / "01_flip.png")), read_png(str(tmp_path / "00_debayer.png")))
+        deb, _ = oracle_run(oracle, prefix_cfg(c, 1), frame, "bayer_gbrg8")
+        assert np.array_equal(read_png(str(tmp_path / "00_debayer.png")), normalize_minmax(deb))
+    mono = synth.gen_frame(w, h, "bayer_gbrg8", seed=5, kind="scene")  # any single-channel image
+    c1 = cfg(gamma=True, gamma_k=0.8)
+    configure(pipe, c1)
+    got = pipe.process(mono, "mono8")
+    ref, _ = oracle_run(oracle, c1, mono, "mono8")
+    assert_images_equal(got.reshape(ref.shape), ref, "mono8 with debug on")
+    for k, name in enumerate(DUMP_NAMES):
+        img = read_png(str(tmp_path / (name + ".png")))
+        assert img.ndim == 2
+        assert np.array_equal(img, normalize_minmax(ref if k >= 4 else mono).reshape(h, w)), name
