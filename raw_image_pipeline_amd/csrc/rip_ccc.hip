@@ -229,41 +229,119 @@ __device__ __forceinline__ void fft256_lds(float* re, float* im, const float* tw
 // column are evaluated exactly as fft256_lds does, so the response is unchanged bit for bit.
 constexpr int kFftCols = 16, kFftPitch = 257;  // odd pitch: the 16 columns of one element fall into 16 banks
 
-// 256-point FFTs of kFftCols columns held as re/im[c * kFftPitch + i]; 256 threads: column t & 15, eight
-// butterflies of every stage each
+// 256-point FFTs of kFftCols columns held as re/im[c * kFftPitch + i] (bit-reversed input on entry, after a barrier;
+// natural-order output, followed by a barrier); 256 threads: column t & 15, sixteen elements each.
+//
+// The eight radix-2 stages are the butterflies of fft256_lds / host_fft256 -- same operands, same twiddle index, same
+// operations, so every value is bit-identical -- but scheduled in three register rounds instead of eight LDS passes:
+// stages 2-4-8 on eight contiguous elements, stages 16-32-64 on eight elements 8 apart, stages 128-256 on four elements
+// 64 apart.  A thread loads its elements, runs the stages of the round in registers and stores them back: 6 LDS accesses
+// per element and 3 barriers per transform instead of 16 and 16 (the transforms were LDS-bound).
+__device__ __forceinline__ void fft_bfly(float& ur, float& ui, float& xr, float& xi, float wr, float wi) {
+  const float tr = wr * xr - wi * xi;
+  const float ti = wr * xi + wi * xr;
+  const float lr = ur + tr, li = ui + ti, hr = ur - tr, hi = ui - ti;
+  ur = lr;
+  ui = li;
+  xr = hr;
+  xi = hi;
+}
+
 __device__ __forceinline__ void fft256_columns_lds(float* re, float* im, const float* twr, const float* twi, bool inverse) {
-  const int c = threadIdx.x & (kFftCols - 1), b0 = threadIdx.x >> 4;
+  const int c = threadIdx.x & (kFftCols - 1), g = threadIdx.x >> 4;
   float* cre = re + c * kFftPitch;
   float* cim = im + c * kFftPitch;
-  for (int len = 2; len <= 256; len <<= 1) {
-    const int half = len >> 1, tstep = 256 / len;
-    float nr[8][2], ni[8][2];
+  auto tw = [&](int idx, float& wr, float& wi) {
+    wr = twr[idx];
+    wi = inverse ? -twi[idx] : twi[idx];
+  };
+  // round A: stages len = 2, 4, 8 on elements B .. B + 7
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int b = b0 + 16 * m;
-      const int k = b & (half - 1), lo = (b / half) * len + k, hi = lo + half;
-      const float wr = twr[k * tstep], wi = inverse ? -twi[k * tstep] : twi[k * tstep];
-      const float xr = cre[hi], xi = cim[hi];
-      const float tr = wr * xr - wi * xi;
-      const float ti = wr * xi + wi * xr;
-      const float ur = cre[lo], ui = cim[lo];
-      nr[m][0] = ur + tr;
-      ni[m][0] = ui + ti;
-      nr[m][1] = ur - tr;
-      ni[m][1] = ui - ti;
-    }
-    __syncthreads();
+  for (int h = 0; h < 2; h++) {
+    const int B = 8 * (2 * g + h);
+    float xr[8], xi[8], wr, wi;
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int b = b0 + 16 * m;
-      const int k = b & (half - 1), lo = (b / half) * len + k, hi = lo + half;
-      cre[lo] = nr[m][0];
-      cim[lo] = ni[m][0];
-      cre[hi] = nr[m][1];
-      cim[hi] = ni[m][1];
+    for (int j = 0; j < 8; j++) {
+      xr[j] = cre[B + j];
+      xi[j] = cim[B + j];
     }
-    __syncthreads();
+    tw(0, wr, wi);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) fft_bfly(xr[j], xi[j], xr[j + 1], xi[j + 1], wr, wi);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      tw(j * 64, wr, wi);
+      fft_bfly(xr[j], xi[j], xr[j + 2], xi[j + 2], wr, wi);
+      fft_bfly(xr[j + 4], xi[j + 4], xr[j + 6], xi[j + 6], wr, wi);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      tw(j * 32, wr, wi);
+      fft_bfly(xr[j], xi[j], xr[j + 4], xi[j + 4], wr, wi);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {  // a thread's own elements: no barrier needed before the store
+      cre[B + j] = xr[j];
+      cim[B + j] = xi[j];
+    }
   }
+  __syncthreads();
+  // round B: stages len = 16, 32, 64 on elements B64 + r + 8 m
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int q = 2 * g + h, base = (q >> 3) * 64 + (q & 7), r = q & 7;
+    float xr[8], xi[8], wr, wi;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      xr[m] = cre[base + 8 * m];
+      xi[m] = cim[base + 8 * m];
+    }
+    tw(r * 16, wr, wi);
+#pragma unroll
+    for (int m = 0; m < 8; m += 2) fft_bfly(xr[m], xi[m], xr[m + 1], xi[m + 1], wr, wi);
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      tw((r + 8 * m) * 8, wr, wi);
+      fft_bfly(xr[m], xi[m], xr[m + 2], xi[m + 2], wr, wi);
+      fft_bfly(xr[m + 4], xi[m + 4], xr[m + 6], xi[m + 6], wr, wi);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      tw((r + 8 * m) * 4, wr, wi);
+      fft_bfly(xr[m], xi[m], xr[m + 4], xi[m + 4], wr, wi);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      cre[base + 8 * m] = xr[m];
+      cim[base + 8 * m] = xi[m];
+    }
+  }
+  __syncthreads();
+  // round C: stages len = 128, 256 on elements r + 64 m; the four row groups of a wave sit 16 apart (two lanes per bank)
+#pragma unroll
+  for (int h = 0; h < 4; h++) {
+    const int r = 16 * (g & 3) + (g >> 2) + 4 * h;
+    float xr[4], xi[4], wr, wi;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      xr[m] = cre[r + 64 * m];
+      xi[m] = cim[r + 64 * m];
+    }
+    tw(r * 2, wr, wi);
+    fft_bfly(xr[0], xi[0], xr[1], xi[1], wr, wi);
+    fft_bfly(xr[2], xi[2], xr[3], xi[3], wr, wi);
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      tw(r + 64 * m, wr, wi);
+      fft_bfly(xr[m], xi[m], xr[m + 2], xi[m + 2], wr, wi);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      cre[r + 64 * m] = xr[m];
+      cim[r + 64 * m] = xi[m];
+    }
+  }
+  __syncthreads();
 }
 
 // Row transforms, kFftCols rows per 256-thread workgroup on the same slab code (a row is 1 KB of contiguous floats, so
