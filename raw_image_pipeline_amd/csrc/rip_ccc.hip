@@ -20,13 +20,13 @@ __device__ __forceinline__ void fetch_flipped(const SrcView& s, int angle, int y
 // Demosaic of the 2x2 block whose top-left pixel is (y, x), all four pixels interior (no border rule):
 // the 4x4 raw window around it is read with two aligned dwords per row instead of nine byte loads per
 // pixel.  Every 2x2 block holds one site of each kind; out[i * 2 + j] = pixel (y + i, x + j) as b, g, r.
-__device__ __forceinline__ void debayer_block2x2(const SrcView& s, int y, int x, int (&out)[4][3]) {
+// lo / hi: the two aligned dwords that hold bytes x - 1 .. x + 2 of rows y - 1 .. y + 2; sh: byte offset of x - 1 in lo
+__device__ __forceinline__ void debayer_block2x2_win(const SrcView& s, int y, int x, const uint32_t (&lo)[4], const uint32_t (&hi)[4], unsigned sh,
+                                                     int (&out)[4][3]) {
   int v[4][4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const unsigned off = __umul24((unsigned)(y - 1 + r), (unsigned)s.step) + (unsigned)(x - 1);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(s.base + (off & ~3u));
-    const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], off & 3u);
+    const uint32_t w = __builtin_amdgcn_alignbyte(hi[r], lo[r], sh);
 #pragma unroll
     for (int c = 0; c < 4; c++) v[r][c] = (int)((w >> (8 * c)) & 0xFFu);
   }
@@ -56,10 +56,60 @@ __device__ __forceinline__ void debayer_block2x2(const SrcView& s, int y, int x,
     }
 }
 
+__device__ __forceinline__ void debayer_block2x2(const SrcView& s, int y, int x, int (&out)[4][3]) {
+  uint32_t lo[4], hi[4];
+  unsigned sh = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const unsigned off = __umul24((unsigned)(y - 1 + r), (unsigned)s.step) + (unsigned)(x - 1);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(s.base + (off & ~3u));
+    lo[r] = q[0];
+    hi[r] = q[1];
+    sh = off & 3u;  // step % 4 == 0 on this path: the same for the four rows
+  }
+  debayer_block2x2_win(s, y, x, lo, hi, sh, out);
+}
+
+// The same 2x2 block in packed form.  The 4x4 window is four dwords (bytes = columns x - 1 .. x + 2); every candidate value
+// of the two block columns -- centre, horizontal / vertical two-tap, cross and diagonal four-tap averages -- is evaluated for
+// both columns at once with v_lerp_u8 (the identities of the fused chain's demosaic, rip_device.hpp), and the site kinds,
+// which differ from lane to lane with the block's parity, pick bytes with v_cndmask / v_perm.
+// pair[i][c]: channel c (b, g, r) of block row i as two 16-bit fields, left pixel | right pixel << 16.
+__device__ __forceinline__ void debayer_block2x2_pairs(const SrcView& s, int y, int x, const uint32_t (&lo)[4], const uint32_t (&hi)[4],
+                                                       unsigned sh, uint32_t (&pair)[2][3]) {
+  constexpr uint32_t kOnes = 0x01010101u;
+  uint32_t W[4], H[4], NXH[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    W[r] = __builtin_amdgcn_alignbyte(hi[r], lo[r], sh);
+    const uint32_t left = W[r] << 8, right = W[r] >> 8;  // byte j: column j - 1 / j + 1 of the window
+    H[r] = __builtin_amdgcn_lerp(left, right, kOnes);
+    NXH[r] = ~(left ^ right);
+  }
+  const bool py = ((y - s.ry) & 1) != 0, px = ((x - s.rx) & 1) != 0;  // parity of the block's top-left pixel: (0, 0) = R site
+  // bytes 1 and 2 of the sources go to the low halves of the two 16-bit fields; with px the columns swap site kinds
+  const uint32_t sel = px ? 0x0c020c05u : 0x0c060c01u;  // perm(S0 = odd-column kind, S1 = even-column kind)
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const uint32_t C = W[i + 1];
+    const uint32_t V = __builtin_amdgcn_lerp(W[i], W[i + 2], kOnes);
+    const uint32_t X4 = __builtin_amdgcn_lerp(H[i + 1], V, NXH[i + 1] & ~(W[i] ^ W[i + 2]));
+    const uint32_t D4 = __builtin_amdgcn_lerp(H[i], H[i + 2], NXH[i] & NXH[i + 2]);
+    const bool dy = py != (i != 0);  // red row: dy == 0
+    // value at an even-parity column (dx == 0) / odd-parity column (dx == 1) of this row
+    const uint32_t r0 = dy ? V : C, r1 = dy ? D4 : H[i + 1];
+    const uint32_t b0 = dy ? H[i + 1] : D4, b1 = dy ? C : V;
+    const uint32_t g0 = dy ? C : X4, g1 = dy ? X4 : C;
+    pair[i][0] = __builtin_amdgcn_perm(b1, b0, sel);
+    pair[i][1] = __builtin_amdgcn_perm(g1, g0, sel);
+    pair[i][2] = __builtin_amdgcn_perm(r1, r0, sel);
+  }
+}
+
 // the 2x2 block of post-flip pixels at (y, x): fast window path for unflipped Bayer frames, else per pixel
 __device__ __forceinline__ void fetch_block2x2(const SrcView& s, int angle, int y, int x, int y1, int x1, int (&out)[4][3]) {
   const bool fast = s.kind == SRC_BAYER && angle == 0 && y1 == y + 1 && x1 == x + 1 && y >= 1 && y1 <= s.rows - 2 && x >= 1 &&
-                    x1 <= s.cols - 2 && (unsigned)(x + 6) < (unsigned)s.step && (reinterpret_cast<uintptr_t>(s.base) & 3u) == 0 &&
+                    x1 <= s.cols - 2 && ((unsigned)(x + 6) < (unsigned)s.step || y + 2 < s.rows - 1) && (reinterpret_cast<uintptr_t>(s.base) & 3u) == 0 &&
                     (s.step & 3u) == 0 && (unsigned long long)s.step * (unsigned long long)s.rows < (1ull << 32) && s.step < (1u << 24);
   if (fast) {
     debayer_block2x2(s, y, x, out);
@@ -70,6 +120,9 @@ __device__ __forceinline__ void fetch_block2x2(const SrcView& s, int angle, int 
   fetch_flipped(s, angle, y1, x, out[2][0], out[2][1], out[2][2]);
   fetch_flipped(s, angle, y1, x1, out[3][0], out[3][1], out[3][2]);
 }
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
 // Samples per frame: 360 x 270 (small_size_, convolutional_color_constancy.cpp:22).  The resize geometry and the log
 // table live in LDS (ten table reads per sample otherwise go to L2).
@@ -88,6 +141,22 @@ struct CccSampleTabs {
     for (int i = threadIdx.x; i < 256; i += NT) logt[i] = p.tabs->log_tab[i];
   }
 };
+
+// Grey mask and log-chroma bin of one resized sample (b, g, r); -1 when the sample is masked out
+// (calculateHistogramFeature :210-271).  Branch-free: straight-line callers keep several samples in flight.
+__device__ __forceinline__ int ccc_bin_of(const CccParams& p, const CccSampleTabs& tb, const int (&sm)[3]) {
+  float fb = (float)sm[0], fg = (float)sm[1], fr = (float)sm[2];
+  float gray = fb * 0.114f + fg * 0.587f + fr * 0.299f;
+  bool ok = !(gray > p.upper) && (gray > p.lower);
+  if (sm[0] == 0 || sm[1] == 0 || sm[2] == 0) ok = false;  // log(0) = -inf is skipped
+  const float bin_size = 1.0f / 64.0f, uv0 = -1.421875f;
+  float lb = tb.logt[sm[0]], lg = tb.logt[sm[1]], lr = tb.logt[sm[2]];
+  int u = (int)roundf((lg - lr - uv0) / bin_size);
+  int v = (int)roundf((lg - lb - uv0) / bin_size);
+  u = clampi(u, 0, 255);
+  v = clampi(v, 0, 255);
+  return ok ? u * 256 + v : -1;
+}
 
 // Sample i of the 360 x 270 grid: cv::resize tap arithmetic, grey mask, log-chroma bin.  Returns the bin index
 // u * 256 + v (hist.at(u, v), :260), or -1 when the sample is masked out (calculateHistogramFeature :210-271).
@@ -114,18 +183,105 @@ __device__ __forceinline__ int ccc_sample_bin(const CccParams& p, const CccSampl
       sm[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
     }
   }
-  float fb = (float)sm[0], fg = (float)sm[1], fr = (float)sm[2];
-  float gray = fb * 0.114f + fg * 0.587f + fr * 0.299f;
-  bool ok = !(gray > p.upper) && (gray > p.lower);
-  if (sm[0] == 0 || sm[1] == 0 || sm[2] == 0) ok = false;  // log(0) = -inf is skipped
-  if (!ok) return -1;
-  const float bin_size = 1.0f / 64.0f, uv0 = -1.421875f;
-  float lb = tb.logt[sm[0]], lg = tb.logt[sm[1]], lr = tb.logt[sm[2]];
-  int u = (int)roundf((lg - lr - uv0) / bin_size);
-  int v = (int)roundf((lg - lb - uv0) / bin_size);
-  u = clampi(u, 0, 255);
-  v = clampi(v, 0, 255);
-  return u * 256 + v;
+  return ccc_bin_of(p, tb, sm);
+}
+
+// K samples of one lane in straight-line code.  ccc_sample_bin branches per sample (resize mode, window path, mask), so the
+// compiler cannot start a sample's loads before the previous sample is finished and every sample pays its own chain of
+// latencies (table lookups -> eight window loads -> log table -> histogram atomic: the LDS-histogram kernel sat in s_waitcnt
+// for 64 % of its wave cycles).  Here the geometry of all K samples is looked up first and checked once for the wave; when
+// every lane's K blocks are interior 2x2 blocks of an unflipped, dword-aligned Bayer frame (every sample of the usual
+// geometries) the 8 K loads are issued together and the arithmetic follows -- same operations, same results.
+struct CccSampleGeom {
+  int y, x, b0, b1;   // top-left pixel of the 2x2 block; Q11 row weights (unused by the exact-2x area mode)
+  uint32_t alpha2;    // Q11 column weights, left | right << 16
+  bool straight;             // interior 2x2 block with y1 == y + 1, x1 == x + 1
+};
+__device__ __forceinline__ CccSampleGeom ccc_sample_geom(const CccParams& p, const CccSampleTabs& tb, const SrcView& s, int i) {
+  const int dy = i / 360, dx = i - dy * 360;
+  CccSampleGeom g;
+  int y1, x1;
+  if (p.geom.area_fast) {  // uniform
+    g.y = 2 * dy;
+    g.x = 2 * dx;
+    y1 = g.y + 1;
+    x1 = g.x + 1;
+    g.b0 = g.b1 = 0;
+    g.alpha2 = 0;
+  } else {
+    g.x = tb.xofs[dx];
+    x1 = g.x + 1 < p.dcols ? g.x + 1 : g.x;
+    g.alpha2 = reinterpret_cast<const uint32_t*>(tb.ialpha)[dx];  // ialpha[2 dx], ialpha[2 dx + 1]
+    g.y = tb.yofs[dy * 2];
+    y1 = tb.yofs[dy * 2 + 1];
+    g.b0 = tb.ibeta[dy * 2];
+    g.b1 = tb.ibeta[dy * 2 + 1];
+  }
+  // the two dwords of a window row end at most at byte x + 6 of that row: past the row's end that is the next row of the
+  // frame, except in the frame's last row (y + 2 == rows - 1), where it could leave the buffer
+  g.straight = y1 == g.y + 1 && x1 == g.x + 1 && g.y >= 1 && y1 <= s.rows - 2 && g.x >= 1 && x1 <= s.cols - 2 &&
+               ((unsigned)(g.x + 6) < (unsigned)s.step || g.y + 2 < s.rows - 1);
+  return g;
+}
+// frame-level part of fetch_block2x2's window-path condition (wave-uniform)
+__device__ __forceinline__ bool ccc_frame_straight(const CccParams& p, const SrcView& s) {
+  return s.kind == SRC_BAYER && p.flip_angle == 0 && (reinterpret_cast<uintptr_t>(s.base) & 3u) == 0 && (s.step & 3u) == 0 &&
+         (unsigned long long)s.step * (unsigned long long)s.rows < (1ull << 32) && s.step < (1u << 24);
+}
+
+template <int K>
+__device__ __forceinline__ void ccc_sample_bins(const CccParams& p, const CccSampleTabs& tb, const SrcView& s, bool frame_straight,
+                                                const int (&idx)[K], const bool (&live)[K], int (&bin)[K]) {
+  CccSampleGeom g[K];
+  bool all = frame_straight;
+  if (frame_straight) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      g[k] = ccc_sample_geom(p, tb, s, idx[k]);
+      all = all && g[k].straight;
+    }
+    all = __builtin_amdgcn_ballot_w64(!all) == 0ull;  // every active lane
+  }
+  if (!all) {
+#pragma unroll
+    for (int k = 0; k < K; k++) bin[k] = live[k] ? ccc_sample_bin(p, tb, s, idx[k]) : -1;
+    return;
+  }
+  uint32_t lo[K][4], hi[K][4];
+  unsigned sh[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const unsigned off = __umul24((unsigned)(g[k].y - 1 + r), (unsigned)s.step) + (unsigned)(g[k].x - 1);
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(s.base + (off & ~3u));
+      lo[k][r] = q[0];
+      hi[k][r] = q[1];
+      if (r == 0) sh[k] = off & 3u;  // step % 4 == 0: the same for the four rows
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    uint32_t pr[2][3];
+    debayer_block2x2_pairs(s, g[k].y, g[k].x, lo[k], hi[k], sh[k], pr);
+    int sm[3];
+    if (p.geom.area_fast) {
+      const u16x2 one2 = as_u16x2(0x00010001u);
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        sm[c] = (int)(__builtin_amdgcn_udot2(as_u16x2(pr[1][c]), one2, __builtin_amdgcn_udot2(as_u16x2(pr[0][c]), one2, 2u, false), false) >> 2);
+    } else {
+      const u16x2 alpha = as_u16x2(g[k].alpha2);  // Q11 taps of the two columns, non-negative
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const unsigned r0 = __builtin_amdgcn_udot2(as_u16x2(pr[0][c]), alpha, 0u, false);
+        const unsigned r1 = __builtin_amdgcn_udot2(as_u16x2(pr[1][c]), alpha, 0u, false);
+        sm[c] = (int)(((__umul24((unsigned)g[k].b0, r0 >> 4) >> 16) + (__umul24((unsigned)g[k].b1, r1 >> 4) >> 16) + 2u) >> 2);
+      }
+    }
+    const int b = ccc_bin_of(p, tb, sm);
+    bin[k] = live[k] ? b : -1;
+  }
 }
 
 // Small batches: kHistBlocks workgroups per frame, one global atomic per sample into a zeroed histogram (a frame's
@@ -149,6 +305,9 @@ __global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
 // receives more than 65 535 of the 97 200 samples (a flat frame).  At most one bin per frame can do that, and only once;
 // the returning atomic shows the wrap (old half == 0xFFFF), the carry into the neighbouring bin is taken back and the
 // bin is remembered, so the written count is exact.  Counts are integers: the result does not depend on the order.
+#ifndef RIP_CCC_UNROLL
+#define RIP_CCC_UNROLL 2
+#endif
 constexpr int kHistLdsThreads = 1024, kHistWords = 32768;
 __global__ __launch_bounds__(kHistLdsThreads) void ccc_hist_lds_kernel(CccParams p) {
   extern __shared__ __align__(16) unsigned char ccc_smem[];
@@ -162,15 +321,19 @@ __global__ __launch_bounds__(kHistLdsThreads) void ccc_hist_lds_kernel(CccParams
   __syncthreads();
   const int frame = blockIdx.x;
   SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
-  // two independent samples per thread and trip: their tap loads are in flight together
-  constexpr int kUnroll = 2;
+  // RIP_CCC_UNROLL independent samples per thread and trip, their window loads in flight together (ccc_sample_bins)
+  constexpr int kUnroll = RIP_CCC_UNROLL;
+  const bool frame_straight = ccc_frame_straight(p, s);
   for (int i0 = threadIdx.x; i0 < 360 * 270; i0 += kUnroll * kHistLdsThreads) {
-    int bin[kUnroll];
+    int bin[kUnroll], idx[kUnroll];
+    bool live[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       const int i = i0 + k * kHistLdsThreads;
-      bin[k] = i < 360 * 270 ? ccc_sample_bin(p, tb, s, i) : -1;
+      live[k] = i < 360 * 270;
+      idx[k] = live[k] ? i : 360 * 270 - 1;
     }
+    ccc_sample_bins<kUnroll>(p, tb, s, frame_straight, idx, live, bin);
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       if (bin[k] < 0) continue;
