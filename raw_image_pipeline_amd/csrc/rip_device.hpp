@@ -819,6 +819,52 @@ __device__ __forceinline__ void debayer_swar(const Window& win, Planar (&out)[2]
   debayer_rows<RY, RX>(r[0], r[1], r[2], r[3], out);
 }
 
+// One output row (four pixels) from the prepared rows above / at / below it, for any Bayer pattern without a per-pattern
+// code path.  `even`: the byte lanes whose column holds the row's first-listed site kind -- for a red row the R sites.
+// Returns p (diagonal four-tap at those lanes, vertical two-tap at the others), g (cross four-tap / centre) and q (centre /
+// horizontal two-tap): on a red row (b, g, r) = (p, g, q); a blue row is the same computation with the complementary lanes
+// and (b, g, r) = (q, g, p).
+struct RowPgq {
+  uint32_t p, g, q;
+};
+__device__ __forceinline__ RowPgq debayer_row_pgq(const RowPrep& up, const RowPrep& at, const RowPrep& dn, uint32_t even) {
+  const uint32_t H = at.h;
+  const uint32_t V = __builtin_amdgcn_lerp(up.c, dn.c, 0x01010101u);
+  const uint32_t X4 = __builtin_amdgcn_lerp(H, V, ~(at.hx | (up.c ^ dn.c)));     // left, right, up, down
+  const uint32_t D4 = __builtin_amdgcn_lerp(up.h, dn.h, ~(up.hx | dn.hx));       // the four diagonal neighbours
+  const uint32_t C = at.c;
+  return RowPgq{bfi32(even, D4, V), bfi32(even, X4, C), bfi32(even, C, H)};
+}
+
+// ry / rx: position of the R sample in the 2x2 cell (wave-uniform).  out[ly] = image row y0 + ly; r[k] = row y0 - 1 + k.
+// Exactly one of the two rows is a red row: with ry == 0 it is the first, the lanes of its R sites are the columns of
+// parity rx, and the blue row below uses the complementary lanes; with ry == 1 the same code runs with the complementary
+// masks and every (b, r) pair comes out exchanged -- one uniform branch with two register swaps puts them right.  (In the
+// statistics kernel a switch over the four patterns made hipcc evaluate the byte merges of two patterns per tile; the
+// fused chain keeps the switch -- there the templated merges with literal selectors are 2 % faster.)
+__device__ __forceinline__ void debayer_rows_any(const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3, int ry,
+                                                 int rx, Planar (&out)[2]) {
+  const uint32_t lanes_rx = rx == 0 ? 0x00FF00FFu : 0xFF00FF00u;  // columns of parity rx
+  const uint32_t m0 = ry == 0 ? lanes_rx : ~lanes_rx;
+  const RowPgq a = debayer_row_pgq(r0, r1, r2, m0);
+  const RowPgq c = debayer_row_pgq(r1, r2, r3, ~m0);
+  out[0].b = a.p;
+  out[0].g = a.g;
+  out[0].r = a.q;
+  out[1].b = c.q;
+  out[1].g = c.g;
+  out[1].r = c.p;
+  if (ry != 0) {
+    keep_branch();
+    uint32_t t = out[0].b;
+    out[0].b = out[0].r;
+    out[0].r = t;
+    t = out[1].b;
+    out[1].b = out[1].r;
+    out[1].r = t;
+  }
+}
+
 // OpenCV's border replication on a demosaiced 4x2 tile: column 0 := column 1, column W-1 := W-2,
 // then row 0 := row 1, row H-1 := H-2
 __device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int cols, Planar (&out)[2]) {
@@ -844,16 +890,6 @@ __device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int 
   if (y0 == 0) out[0] = out[1];
   if (y0 + 2 == rows) out[1] = out[0];
 }
-__device__ __forceinline__ void debayer_rows_any(const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3, int ry,
-                                                 int rx, Planar (&out)[2]) {
-  switch (ry * 2 + rx) {
-    case 0: debayer_rows<0, 0>(r0, r1, r2, r3, out); break;
-    case 1: debayer_rows<0, 1>(r0, r1, r2, r3, out); break;
-    case 2: debayer_rows<1, 0>(r0, r1, r2, r3, out); break;
-    default: debayer_rows<1, 1>(r0, r1, r2, r3, out); break;
-  }
-}
-
 // demosaic of the 4x2 tile at (y0, x0) including OpenCV's border replication
 __device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int rx, int y0, int x0, int rows, int cols,
                                                  Planar (&out)[2]) {

@@ -106,7 +106,13 @@ __device__ __forceinline__ void grayworld_add_swar(const Planar& v, unsigned thr
     const u16x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(b2, g2), r2);
     const u16x2 lhs = mn * c255 + one2;  // 255 * min + 1 <= 65026
     const u16x2 rhs = mx * s2;           // (255 - thresh255) * max <= 65025
-    const u16x2 keep = __builtin_elementwise_min(__builtin_elementwise_sub_sat(lhs, rhs), one2);  // 1 where lhs > rhs
+    // 1 where lhs > rhs.  Written out: hipcc turns min(sub_sat(lhs, rhs), 1) into two 16-bit compares, two selects and a
+    // byte merge (five instructions and two hazard nops)
+    uint32_t keep_bits;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3"
+        : "=&v"(keep_bits)
+        : "v"(__builtin_bit_cast(uint32_t, lhs)), "v"(__builtin_bit_cast(uint32_t, rhs)), "v"(0x00010001u));
+    const u16x2 keep = as_u16x2(keep_bits);
     a.s[0] = __builtin_amdgcn_udot2(b2, keep, a.s[0], false);
     a.s[1] = __builtin_amdgcn_udot2(g2, keep, a.s[1], false);
     a.s[2] = __builtin_amdgcn_udot2(r2, keep, a.s[2], false);
