@@ -92,31 +92,37 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
 // (255 - thresh255) * max < 255 * min + 1: both sides fit 16 bits (thresh255 <= 255 after the clamp below, which does not change
 // the outcome: for thresh255 >= 255 no pixel is ever skipped), so the 0/1 keep flag is min(sat_sub(255 * min + 1, s * max), 1) --
 // one packed multiply-add, one packed multiply, one saturating subtract, one min -- and the masked channel sums are one
-// v_dot2_u32_u16 per channel with the flags as weights.
+// v_dot4_u32_u8 per channel on the packed pixels with the four flags as byte weights.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t gw_keep_pair(uint32_t mx, uint32_t mn, uint32_t s2, uint32_t c255) {
+  // 0 / 1 in both 16-bit fields: 1 where 255 * min + 1 > (255 - thresh255) * max.  Written out: hipcc turns
+  // min(sub_sat(lhs, rhs), 1) into two 16-bit compares, two selects and a byte merge (five instructions and two hazard nops)
+  const u16x2 lhs = as_u16x2(mn) * as_u16x2(c255) + as_u16x2(0x00010001u);  // <= 65026
+  const u16x2 rhs = as_u16x2(mx) * as_u16x2(s2);                            // <= 65025
+  uint32_t keep;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3"
+      : "=&v"(keep)
+      : "v"(__builtin_bit_cast(uint32_t, lhs)), "v"(__builtin_bit_cast(uint32_t, rhs)), "v"(0x00010001u));
+  return keep;
+}
 __device__ __forceinline__ void grayworld_add_swar(const Planar& v, unsigned thresh255, StatAcc& a) {
   constexpr uint32_t M8 = 0x00FF00FFu;
-  const u16x2 s2 = as_u16x2((255u - thresh255) * 0x00010001u), one2 = as_u16x2(0x00010001u), c255 = as_u16x2(0x00FF00FFu);
-#pragma unroll
-  for (int half = 0; half < 2; half++) {
-    const uint32_t bw = (half ? v.b >> 8 : v.b) & M8, gw = (half ? v.g >> 8 : v.g) & M8, rw = (half ? v.r >> 8 : v.r) & M8;
-    const u16x2 b2 = as_u16x2(bw), g2 = as_u16x2(gw), r2 = as_u16x2(rw);
-    const u16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(b2, g2), r2);
-    const u16x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(b2, g2), r2);
-    const u16x2 lhs = mn * c255 + one2;  // 255 * min + 1 <= 65026
-    const u16x2 rhs = mx * s2;           // (255 - thresh255) * max <= 65025
-    // 1 where lhs > rhs.  Written out: hipcc turns min(sub_sat(lhs, rhs), 1) into two 16-bit compares, two selects and a
-    // byte merge (five instructions and two hazard nops)
-    uint32_t keep_bits;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3"
-        : "=&v"(keep_bits)
-        : "v"(__builtin_bit_cast(uint32_t, lhs)), "v"(__builtin_bit_cast(uint32_t, rhs)), "v"(0x00010001u));
-    const u16x2 keep = as_u16x2(keep_bits);
-    a.s[0] = __builtin_amdgcn_udot2(b2, keep, a.s[0], false);
-    a.s[1] = __builtin_amdgcn_udot2(g2, keep, a.s[1], false);
-    a.s[2] = __builtin_amdgcn_udot2(r2, keep, a.s[2], false);
-  }
+  const uint32_t s2 = (255u - thresh255) * 0x00010001u, c255 = 0x00FF00FFu;
+  // pixels 0 and 2: bytes widened to 16-bit fields
+  const u16x2 be = as_u16x2(v.b & M8), ge = as_u16x2(v.g & M8), re = as_u16x2(v.r & M8);
+  const uint32_t mxe = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_elementwise_max(be, ge), re));
+  const uint32_t mne = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_min(be, ge), re));
+  // pixels 1 and 3: a 16-bit max / min of the raw dwords is decided by the high bytes (the low byte only breaks ties
+  // between equal high bytes), so the high byte of every field is the max / min of those pixels -- no masking of the inputs
+  const u16x2 braw = as_u16x2(v.b), graw = as_u16x2(v.g), rraw = as_u16x2(v.r);
+  const uint32_t mxo = (__builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_elementwise_max(braw, graw), rraw)) >> 8) & M8;
+  const uint32_t mno = (__builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_min(braw, graw), rraw)) >> 8) & M8;
+  // keep flags of the four pixels as bytes 0 / 1: the weights of one v_dot4_u32_u8 per channel on the packed pixels
+  const uint32_t keep = gw_keep_pair(mxe, mne, s2, c255) | (gw_keep_pair(mxo, mno, s2, c255) << 8);
+  a.s[0] = __builtin_amdgcn_udot4(v.b, keep, a.s[0], false);
+  a.s[1] = __builtin_amdgcn_udot4(v.g, keep, a.s[1], false);
+  a.s[2] = __builtin_amdgcn_udot4(v.r, keep, a.s[2], false);
 }
 
 // Statistics of a Bayer frame.  A wave owns a strip 64 groups (256 px) wide and walks down
