@@ -267,43 +267,50 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
         s_raw[i][1] = ccc_argmax[2 * (f0 + i) + 1];
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        CccState s = s_state;
+      // A = Q = I, H = h I, R = r I: the two components of (u, v) never mix, so lane a walks component a (half the
+      // dependent float chain -- an IEEE division per step -- of a single lane doing both)
+      if (threadIdx.x < 2) {
+        const int a = threadIdx.x;
+        const bool temporal = s_state.temporal != 0;
+        bool first = s_state.first_frame != 0;
+        float x = a == 0 ? s_state.st_x : s_state.st_y, pc = a == 0 ? s_state.p_x : s_state.p_y;
+        const float kf_h = s_state.kf_h, kf_r = s_state.kf_r;
+        int last = a == 0 ? s_state.uv_x : s_state.uv_y;
         for (int i = 0; i < n; i++) {
-          s.uv_x = s_raw[i][0];
-          s.uv_y = s_raw[i][1];
-          if (s.temporal) {
-            if (s.first_frame) {
-              s.first_frame = 0;
-              s.st_x = (float)s.uv_x;
-              s.st_y = (float)s.uv_y;
+          const int z = s_raw[i][a];
+          int o = z;
+          if (temporal) {
+            if (first) {
+              first = false;
+              x = (float)z;
             } else {
-              // cv::KalmanFilter(2,2,0) predict + correct with A = I, Q = I, H = h I, R = r I
-              float xs[2] = {s.st_x, s.st_y}, ps[2] = {s.p_x, s.p_y};
-              int z[2] = {s.uv_x, s.uv_y}, o[2];
-              for (int a = 0; a < 2; a++) {
-                float x_pre = xs[a];
-                float p_pre = ps[a] + 1.0f;
-                float t2 = s.kf_h * p_pre;
-                float t3 = t2 * s.kf_h + s.kf_r;
-                float k = t2 / t3;
-                float innov = (float)z[a] - s.kf_h * x_pre;
-                xs[a] = x_pre + k * innov;
-                ps[a] = p_pre - k * t2;
-                o[a] = (int)xs[a];
-              }
-              s.st_x = xs[0];
-              s.st_y = xs[1];
-              s.p_x = ps[0];
-              s.p_y = ps[1];
-              s.uv_x = o[0];
-              s.uv_y = o[1];
+              // cv::KalmanFilter(2,2,0) predict + correct
+              const float x_pre = x;
+              const float p_pre = pc + 1.0f;
+              const float t2 = kf_h * p_pre;
+              const float t3 = t2 * kf_h + kf_r;
+              const float k = t2 / t3;
+              const float innov = (float)z - kf_h * x_pre;
+              x = x_pre + k * innov;
+              pc = p_pre - k * t2;
+              o = (int)x;
             }
           }
-          s_flt[i][0] = s.uv_x;
-          s_flt[i][1] = s.uv_y;
+          s_flt[i][a] = o;
+          last = o;
         }
-        s_state = s;
+        // both lanes have read s_state before either writes it: they run in lockstep within the wave
+        __builtin_amdgcn_wave_barrier();
+        if (a == 0) {
+          s_state.st_x = x;
+          s_state.p_x = pc;
+          s_state.uv_x = last;
+          if (n > 0 && temporal) s_state.first_frame = 0;
+        } else {
+          s_state.st_y = x;
+          s_state.p_y = pc;
+          s_state.uv_y = last;
+        }
       }
       __syncthreads();
       for (int i = threadIdx.x; i < n; i += blockDim.x) {
