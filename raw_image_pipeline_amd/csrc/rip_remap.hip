@@ -122,6 +122,14 @@ __global__ __launch_bounds__(kBlock) void remap_vec4_kernel(RemapParams p, ItemM
 // bilinear weights are applied with v_dot4_u32_u8.  The plan word (4 B/px) and the tile descriptor
 // are read once per tile and reused for every frame of the batch.
 // ------------------------------------------------------------------------------------------------
+// (top * wy0 + bot * wy1) >> 10 with both products on the 24-bit multiplier: one v_mul_u32_u24 + one v_mad_u32_u24.
+// Written out because hipcc proves the operands small, turns the builtins into plain multiplies and then selects the
+// quarter-rate v_mul_lo_u32 for a quarter of them (6 of the 24 per lane and frame).
+__device__ __forceinline__ int blend_rows(unsigned top, unsigned wy0, unsigned bot, unsigned wy1) {
+  unsigned acc;
+  asm("v_mul_u32_u24 %0, %1, %2\n\tv_mad_u32_u24 %0, %3, %4, %0" : "=&v"(acc) : "v"(top), "v"(wy0), "v"(bot), "v"(wy1));
+  return (int)(acc >> 10);
+}
 __device__ __forceinline__ void lds_load6(const uint8_t* lds, unsigned a, uint32_t& lo, uint32_t& hi) {
   const uint32_t* w = reinterpret_cast<const uint32_t*>(lds + (a & ~3u));
   const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
@@ -217,9 +225,9 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_tiled_kernel(RemapTil
         const unsigned botB = __builtin_amdgcn_udot4(b0, wB, 16u, false);
         const unsigned botG = __builtin_amdgcn_udot4(b0, wG0, __builtin_amdgcn_udot4(b1, wx1, 16u, false), false);
         const unsigned botR = __builtin_amdgcn_udot4(b0, wR0, __builtin_amdgcn_udot4(b1, wR1, 16u, false), false);
-        q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1)) >> 10);
-        q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1)) >> 10);
-        q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1)) >> 10);
+        q[k][0] = blend_rows(topB, wy0, botB, wy1);
+        q[k][1] = blend_rows(topG, wy0, botG, wy1);
+        q[k][2] = blend_rows(topR, wy0, botR, wy1);
       }
       uint8_t* dst = b.dst + (size_t)f * b.dst_frame_stride;
       store12(dst + dst_off, pack4(q));
@@ -393,9 +401,9 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
         const unsigned botB = __builtin_amdgcn_udot4(b0[k], wB, 16u, false);
         const unsigned botG = __builtin_amdgcn_udot4(b0[k], wG0, __builtin_amdgcn_udot4(b1[k], wx1, 16u, false), false);
         const unsigned botR = __builtin_amdgcn_udot4(b0[k], wR0, __builtin_amdgcn_udot4(b1[k], wR1, 16u, false), false);
-        q[k][0] = (int)((__umul24(topB, wy0) + __umul24(botB, wy1)) >> 10);
-        q[k][1] = (int)((__umul24(topG, wy0) + __umul24(botG, wy1)) >> 10);
-        q[k][2] = (int)((__umul24(topR, wy0) + __umul24(botR, wy1)) >> 10);
+        q[k][0] = blend_rows(topB, wy0, botB, wy1);
+        q[k][1] = blend_rows(topG, wy0, botG, wy1);
+        q[k][2] = blend_rows(topR, wy0, botR, wy1);
       }
       store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, pack4(q));
     };
