@@ -171,8 +171,14 @@ __device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& 
       for (int c = 0; c < 3; c++) q[k][c] = tb.gam.v.lut[q[k][c]];
   }
   if constexpr ((BITS & ST_HSV) != 0) {
+    if (hr.unit == 5u) {  // hue and value gains are 1 (the usual configuration scales the saturation only)
+      keep_branch();
 #pragma unroll
-    for (int k = 0; k < 4; k++) apply_hsv(hr.g, tb, q[k][0], q[k][1], q[k][2], hr.unit);
+      for (int k = 0; k < 4; k++) apply_hsv<5u>(hr.g, tb, q[k][0], q[k][1], q[k][2]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) apply_hsv<0u>(hr.g, tb, q[k][0], q[k][1], q[k][2]);
+    }
   }
 }
 

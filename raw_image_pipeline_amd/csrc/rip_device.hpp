@@ -624,8 +624,9 @@ __device__ __forceinline__ float min_sat(float a, float b) {
 
 // color_enhancer.cpp:38-47: RGB2HSV_b (H in [0,180)), float gain with u8 saturation,
 // HSV2RGB_b (float)
-template <typename Tabs>
-__device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, int& b, int& g, int& r, unsigned unit_gains = 0u) {
+// UNIT: compile-time set of channels whose gain is exactly 1 (bit c: channel c of H, S, V)
+template <unsigned UNIT = 0u, typename Tabs>
+__device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, int& b, int& g, int& r) {
   int v = max(b, max(g, r)), vmin = min(b, min(g, r));
   int diff = v - vmin;
   int s = (mul24(diff, tb.sdiv(v)) + (1 << 11)) >> 12;
@@ -640,22 +641,13 @@ __device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, 
   h += h < 0 ? 180 : 0;
   h = clampi(h, 0, 255);
   // cv::multiply(hsv, Scalar(gains)): saturate_cast<uchar>(float(x) * gain) per channel, then back to float for HSV2RGB_f.
-  // A gain of exactly 1 leaves the 8-bit value as it is (h, s, v are already in [0, 255]): `unit_gains` (bit c set: gain c == 1,
-  // wave-uniform, from the kernel arguments) skips the multiply and the two conversions of such a channel -- the usual
-  // configuration scales the saturation only.
+  // A gain of exactly 1 leaves the 8-bit value as it is (h, s, v are already in [0, 255]), so the multiply and the two
+  // conversions of such a channel can be skipped: UNIT names those channels at compile time (the caller branches once per
+  // row of pixels on the wave-uniform gain pattern; a branch per pixel and channel cost what the skipped work saved).
   float fH = (float)h, fS = (float)s, fV = (float)v;
-  if (!(unit_gains & 1u)) {
-    keep_branch();
-    fH = (float)sat_round_u8(fH * hg[0]);
-  }
-  if (!(unit_gains & 2u)) {
-    keep_branch();
-    fS = (float)sat_round_u8(fS * hg[1]);
-  }
-  if (!(unit_gains & 4u)) {
-    keep_branch();
-    fV = (float)sat_round_u8(fV * hg[2]);
-  }
+  if constexpr (!(UNIT & 1u)) fH = (float)sat_round_u8(fH * hg[0]);
+  if constexpr (!(UNIT & 2u)) fS = (float)sat_round_u8(fS * hg[1]);
+  if constexpr (!(UNIT & 4u)) fV = (float)sat_round_u8(fV * hg[2]);
   float fh = fH, fs = fS * (1.f / 255.f), fv = fV * (1.f / 255.f);
   // HSV2RGB_f (color_hsv.cpp): tab = {v, v(1-s), v(1-s*f), v(1-s*(1-f))}, (b, g, r) = tab[sector_data[sector][..]], i.e.
   // every output channel is v * (1 - s * w) with w in {0, 1, f, 1 - f} chosen by the sector (w = 0 and w = 1 reproduce tab[0]
