@@ -176,8 +176,10 @@ __device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& 
 #pragma unroll
       for (int k = 0; k < 4; k++) apply_hsv<5u>(hr.g, tb, q[k][0], q[k][1], q[k][2]);
     } else {
+      asm volatile("s_nop 0 ; rip_generic_hsv_gains");  // marks the block for tools/chain_ledger.py (bench runs take the other one)
 #pragma unroll
       for (int k = 0; k < 4; k++) apply_hsv<0u>(hr.g, tb, q[k][0], q[k][1], q[k][2]);
+      asm volatile("s_nop 0 ; rip_generic_hsv_end");
     }
   }
 }

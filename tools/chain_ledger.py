@@ -26,7 +26,8 @@ import isa_cycles as ic  # noqa: E402
 VARIANTS = {"config2": "chain_fast_kernelILi7ELi1ELi512E", "chain": "chain_fast_kernelILi7ELi0ELi512E",
             "config3": "chain_fast_kernelILi8ELi2ELi256E", "config5": "chain_fast_kernelILi0ELi0ELi256E"}
 # blocks the benchmark never executes, recognised by an instruction only they contain
-RARE_MARKERS = [("abToXZ linear segment", re.compile(r"0x4ded21")), ("colour bias != 0", None), ("debayered tap", None)]
+RARE_MARKERS = [("abToXZ linear segment", re.compile(r"0x4ded21")), ("colour bias != 0", None), ("debayered tap", None),
+                ("colour enhancer with hue / value gains != 1", re.compile(r"rip_generic_hsv_gains"))]
 LDS_CYCLES = {"ds_read_b32": 2, "ds_read_b64": 2, "ds_read_b128": 4, "ds_read_u8": 2, "ds_read_u16": 2, "ds_read2_b32": 4, "ds_read_b96": 8}
 
 
@@ -102,7 +103,16 @@ def main():
         for wl, pat in VARIANTS.items():
             name, lines = ic.kernel_lines(listing, pat)
             blocks = loop_blocks(lines)
-            rare = [b for b in blocks if any(re.search(r"0x4ded21", t) for t in b["ins"]) or
+            # regions bracketed by marker instructions (laid out contiguously by LLVM): the generic colour-enhancer gains
+            bracketed, inside = set(), False
+            for i, b in enumerate(blocks):
+                if any("rip_generic_hsv_gains" in t for t in b["ins"]):
+                    inside = True
+                if inside:
+                    bracketed.add(i)
+                if any("rip_generic_hsv_end" in t for t in b["ins"]):
+                    inside = False
+            rare = [b for i, b in enumerate(blocks) if i in bracketed or any(re.search(r"0x4ded21", t) for t in b["ins"]) or
                     sum(1 for t in b["ins"] if t.startswith("v_add_f32") and ic.SGPR_SRC.search(t.split(",", 1)[1])) >= 3 or
                     sum(1 for t in b["ins"] if t.startswith("v_perm_b32")) >= 6 and any("buffer_store_dwordx3" in t for t in b["ins"])]
             cyc, cnt, lds = price(blocks)
