@@ -35,6 +35,7 @@ using Mat = cv::Mat;
 namespace detail {
 inline Mat make_u8(int rows, int cols, int channels) { return Mat(rows, cols, CV_8UC(channels)); }
 inline Mat make_f64(int rows, int cols) { return Mat(rows, cols, CV_64F); }
+inline Mat wrap_u8(int rows, int cols, int channels, uint8_t* ptr) { return Mat(rows, cols, CV_8UC(channels), ptr); }
 inline uint8_t* bytes(Mat& m) { return m.data; }
 inline const uint8_t* bytes(const Mat& m) { return m.data; }
 inline double* doubles(Mat& m) { return m.ptr<double>(); }
@@ -87,6 +88,7 @@ struct AssertionError : std::runtime_error {
 namespace detail {
 inline Mat make_u8(int rows, int cols, int channels) { return Mat(rows, cols, channels); }
 inline Mat make_f64(int rows, int cols) { return Mat(rows, cols, 1, true); }
+inline Mat wrap_u8(int rows, int cols, int channels, uint8_t* ptr) { return Mat(rows, cols, channels, ptr); }
 inline uint8_t* bytes(Mat& m) { return m.data; }
 inline const uint8_t* bytes(const Mat& m) { return m.data; }
 inline double* doubles(Mat& m) { return reinterpret_cast<double*>(m.data); }
@@ -106,6 +108,13 @@ class RawImagePipeline {
     check_create(rip_create(device_from_env(), use_gpu ? 1 : 0, params_path.c_str(), calibration_path.c_str(),
                             color_calibration_path.c_str(), &h_));
   }
+  // Not in the reference: the same two constructors with an explicit HIP device ordinal instead of $RIP_DEVICE (one process
+  // that drives several cameras on several GPUs: camera_rig.hpp).
+  RawImagePipeline(bool use_gpu, int device) { check_create(rip_create_default(device, use_gpu ? 1 : 0, &h_)); }
+  RawImagePipeline(bool use_gpu, const std::string& params_path, const std::string& calibration_path,
+                   const std::string& color_calibration_path, int device) {
+    check_create(rip_create(device, use_gpu ? 1 : 0, params_path.c_str(), calibration_path.c_str(), color_calibration_path.c_str(), &h_));
+  }
   ~RawImagePipeline() { rip_destroy(h_); }
   RawImagePipeline(const RawImagePipeline&) = delete;
   RawImagePipeline& operator=(const RawImagePipeline&) = delete;
@@ -121,6 +130,28 @@ class RawImagePipeline {
   }
   // Alternative pipeline that returns a copy
   Mat process(const Mat& image, std::string& encoding) { return run(image, encoding); }
+
+  // Not in the reference: apply() split in two for a streaming caller (an image callback like
+  // raw_image_pipeline_ros.cpp:219-288).  submit() enqueues upload, chain and download of one frame and returns at once;
+  // collect() waits for that frame.  With one frame kept in flight -- collect(previous) after submit(current) -- the PCIe
+  // transfers of neighbouring frames and the kernels overlap (rip.h: rip_submit / rip_collect).  Frames are processed in
+  // submission order.  collect() returns a copy; collectView() a Mat header over the handle's pinned result buffer (no
+  // copy), valid until the next collect*() on this object.
+  uint64_t submit(const Mat& image, const std::string& encoding) {
+    uint64_t ticket = 0;
+    check(rip_submit(h_, detail::bytes(image), image.rows, image.cols, image.channels(), detail::step_of(image), encoding.c_str(), &ticket));
+    return ticket;
+  }
+  Mat collect(uint64_t ticket, std::string& encoding) { return collectView(ticket, encoding).clone(); }
+  Mat collectView(uint64_t ticket, std::string& encoding) {
+    int rows = 0, cols = 0, cn = 0;
+    char enc[32] = {0};
+    const uint8_t* view = nullptr;
+    check(rip_collect(h_, ticket, nullptr, 0, &view, &rows, &cols, &cn, enc));
+    encoding = enc;
+    return detail::wrap_u8(rows, cols, cn, const_cast<uint8_t*>(view));
+  }
+  void setRingDepth(int depth) { check(rip_set_ring_depth(h_, depth)); }
 
   // Loaders (hpp:53-56)
   void loadParams(const std::string& file_path) { check(rip_load_params(h_, file_path.c_str())); }

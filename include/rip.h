@@ -102,6 +102,33 @@ rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, s
                             int n_frames, int rows, int cols, int channels, const char* encoding, void* d_out,
                             size_t out_step, size_t out_frame_stride, void* d_tap_debayered, void* d_tap_color);
 
+/* ---- asynchronous host-memory frames: the path a streaming caller (raw_image_pipeline_ros.cpp:219-288: one host frame
+ * per image callback) uses to keep the GPU and both PCIe directions busy at once --------------------------------------
+ * rip_submit() is apply() split in two.  It uploads `image` (same arguments as rip_apply), enqueues the chain and the
+ * download into a PINNED result buffer owned by the handle, and returns a ticket without waiting for any of it: upload of
+ * frame f + 1, kernels of frame f and download of frame f - 1 run concurrently (three HIP streams, events in between).
+ * Frames are processed in submission order (the ccc Kalman state advances frame by frame, exactly as with rip_apply).
+ * The handle owns `depth` frame slots (rip_set_ring_depth, default 3, 1..16): with all of them in flight one more
+ * rip_submit fails with RIP_ERR_CAPACITY and changes nothing.  A pageable `image` is read before rip_submit returns
+ * (the HIP runtime pins and copies); memory from rip_host_alloc() is read asynchronously and must stay untouched until
+ * the frame's rip_collect().  Debug dumps (rip_set_debug) are written by rip_apply only. */
+rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step,
+                      const char* encoding, uint64_t* ticket);
+/* Waits for the frame of `ticket` (tickets of one handle may be collected in any order) and hands over the result:
+ * copied into `out` (tightly packed, `out_capacity` bytes) when out != NULL, and / or as a pointer to the handle's pinned
+ * buffer in *out_view when out_view != NULL -- no copy.  The view, and the taps rip_get_image returns afterwards (those of
+ * the collected frame), stay valid until the next rip_collect on this handle -- or until a rip_submit finds every other slot
+ * in flight and takes this one: keep at most depth - 1 frames in flight to hold on to a result while submitting.  Geometry /
+ * encoding as rip_apply.  Unknown or already collected ticket: RIP_ERR_INVALID_ARGUMENT. */
+rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t out_capacity, const uint8_t** out_view,
+                       int* out_rows, int* out_cols, int* out_channels, char encoding_out[32]);
+/* Frames the handle keeps in flight (1..16; default 3).  Only while nothing is in flight. */
+rip_status rip_set_ring_depth(rip_pipeline* p, int depth);
+/* Page-locked host memory for frames handed to rip_submit / rip_apply (hipHostMalloc): uploads from it are asynchronous
+ * and run at the full PCIe rate.  NULL when the allocation fails. */
+void* rip_host_alloc(size_t bytes);
+void rip_host_free(void* ptr);
+
 /* Image getters (hpp:134-137, cpp:222-236): copy of the tap of the most recent rip_apply
  * frame.  RIP_IMAGE_RECT_MASK is always empty (rows = cols = 0): the reference never writes
  * rect_mask_ (undistortion.cpp:150-152). */
@@ -133,8 +160,13 @@ rip_status rip_set_gpu(rip_pipeline* p, int use_gpu);                     /* cpp
  * enabled or not -- as the reference's pipeline() does (raw_image_pipeline.hpp:143-172 -> saveDebugImage :179-186: copy,
  * cv::normalize(0, 255, NORM_MINMAX), cv::imwrite): /tmp/00_debayer.png, 01_flip, 02_white_balancing, 03_color_calibration,
  * 04_gamma_correction, 05_vignetting_correction, 06_color_enhancer, 07_undistortion (.png).  The environment variable
- * RIP_DEBUG_DIR replaces /tmp.  The fused kernel is re-run once per module prefix with the gains of the real pass; the
- * PNGs hold the same pixels as the reference's (stored, not compressed).  rip_apply_device() never dumps. */
+ * RIP_DEBUG_DIR (read when the handle is created) replaces /tmp.  The fused kernel is re-run once per module prefix with the
+ * gains of the real pass (outside any rip_profile_begin/end session).  The PNGs (stored, not compressed) hold the reference's
+ * normalisation formula, scale / shift in double applied in float as separate multiply and add; an OpenCV built with FMA3
+ * contracts that pair, so single values on a rounding tie may differ by 1 LSB from such a build.  The file names are fixed,
+ * as in the reference: handles that share a directory overwrite each other's dumps (give each camera its own RIP_DEBUG_DIR).
+ * A file that cannot be written does not fail the frame (cv::imwrite's result is ignored by the reference too); the paths are
+ * left in rip_last_error().  rip_apply_device() never dumps. */
 rip_status rip_set_debug(rip_pipeline* p, int debug);
 
 /* ---- setters (hpp:66-104; cpp:241-383) ---------------------------------------------------- */
@@ -235,6 +267,11 @@ rip_status rip_debug_atan(rip_pipeline* p, const double* in, double* out, int n)
  * writer of rip_set_debug does, after the reference's min-max normalisation when normalize != 0.  No device needed;
  * p may be NULL. */
 rip_status rip_debug_write_png(rip_pipeline* p, const char* path, const uint8_t* image, int rows, int cols, int channels, int normalize);
+/* Launch tunables of this handle (development / test hook; no reference counterpart).  The library reads its environment
+ * overrides once, in rip_create(); this sets one of them afterwards.  Names: "chain_blocks", "chain_frames", "stats_blocks",
+ * "remap_ring", "remap_stages", "remap_per_cu", "remap_frames", "remap_tiled", "ccc_lds_hist_min", "overlap_groups";
+ * value 0 restores the built-in default where the tunable has one.  Unknown names: RIP_ERR_INVALID_ARGUMENT. */
+rip_status rip_set_tunable(rip_pipeline* p, const char* name, int value);
 const char* rip_version(void);
 
 #ifdef __cplusplus

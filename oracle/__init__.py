@@ -62,6 +62,24 @@ def lib():
     return _lib
 
 
+class fp_contraction:
+    """Context manager: the oracle's floating-point contraction model (rip_oracle.c: 0 none -- the default, what the HIP
+    kernels implement --, 1 fused as GCC / Clang contract the float stages on FMA targets, 2 the other association of the
+    colour matrix's dot product).  Process-wide: not for concurrent use."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = lib().ripo_get_fp_contraction()
+        lib().ripo_set_fp_contraction(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ripo_set_fp_contraction(self.prev)
+        return False
+
+
 def _u8(a):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     return a, a.ctypes.data_as(C.c_void_p)

@@ -16,6 +16,23 @@
 #include <string.h>
 
 /* ------------------------------------------------------------------------------------
+ * Floating-point contraction model.  The float stages below restate C expressions of
+ * OpenCV 4.2 (and of the reference's own translation units) that a compiler may or may not
+ * contract into fused multiply-adds: GCC and Clang do so by default wherever the target has
+ * FMA -- every aarch64 build (the reference's Jetson target), x86-64 only in the AVX2 / FMA3
+ * dispatch variants.  Which rounding a given OpenCV binary performs is therefore a property
+ * of its build, not of its source.  Mode 0 (default, what the HIP kernels implement) is the
+ * uncontracted sequence: every product and every sum rounded.  Mode 1 contracts each
+ * expression the way GCC's and Clang's passes do (a multiply feeding an add becomes one fma,
+ * leftmost multiply first).  Mode 2: like 1, but the first sum of the 3-term dot product
+ * takes the SECOND product as the fused one (the other legal association).  The tests bound
+ * the difference between the modes per stage (tests/test_fp_contraction.py).
+ * ---------------------------------------------------------------------------------- */
+static int g_fp_contract = 0;
+void ripo_set_fp_contraction(int mode) { g_fp_contract = (mode == 1 || mode == 2) ? mode : 0; }
+int ripo_get_fp_contraction(void) { return g_fp_contract; }
+
+/* ------------------------------------------------------------------------------------
  * OpenCV scalar helpers (core/fast_math.hpp, core/saturate.hpp)
  * ---------------------------------------------------------------------------------- */
 static inline int cv_round_d(double v) { return (int)lrint(v); }   /* half to even */
@@ -335,6 +352,12 @@ void ripo_wb_pca(uint8_t* d, size_t npix, float coeffs_out[4]) {
     float b2 = b * b, r2 = r * r;
     float bp = b2 * cb[0] + b * cb[1];
     float rp = r2 * cr[0] + r * cr[1];
+    if (g_fp_contract) {
+      /* cv::addWeighted (the MatExpr a*A + b*B): op_add_weighted is v_fma(A, a, v_fma(B, b, 0)) -- a true fma in
+       * NEON / FMA3 builds, so only the second product is rounded on its own */
+      bp = fmaf(b2, cb[0], b * cb[1]);
+      rp = fmaf(r2, cr[0], r * cr[1]);
+    }
     bp = bp > 255.f ? 255.f : bp;
     rp = rp > 255.f ? 255.f : rp;
     d[i * 3] = sat_u8_f(bp);
@@ -724,7 +747,11 @@ void ripo_color_matrix(uint8_t* d, size_t npix, const double m[9], const double 
     float a0 = d[i * 3], a1 = d[i * 3 + 1], a2 = d[i * 3 + 2];
     for (int c = 0; c < 3; c++) {
       float t = a0 * M[c * 3] + a1 * M[c * 3 + 1] + a2 * M[c * 3 + 2];
-      t = t + B[c];
+      if (g_fp_contract == 1) /* (a0*b0 + a1*b1) + a2*b2: fma(a0, b0, a1*b1), then fma(a2, b2, .) */
+        t = fmaf(a2, M[c * 3 + 2], fmaf(a0, M[c * 3], a1 * M[c * 3 + 1]));
+      else if (g_fp_contract == 2)
+        t = fmaf(a2, M[c * 3 + 2], fmaf(a1, M[c * 3 + 1], a0 * M[c * 3]));
+      t = t + B[c]; /* a separate cv::add over the whole Mat: never fused with the product */
       d[i * 3 + c] = sat_u8_f(t);
     }
   }
@@ -961,6 +988,11 @@ void ripo_vignetting_mask(int rows, int cols, double scale, double a2, double a4
     for (int x = 0; x < width; x++) {
       double r = sqrt(pow(y - cy, 2) + pow(x - cx, 2));
       double k = pow(r, 2) * a2 + pow(r, 4) * a4;
+      if (g_fp_contract) { /* the reference's own TU: pow(., 2) is a multiply, both sums of products contract */
+        double dy = y - cy, dx = x - cx;
+        r = sqrt(fma(dy, dy, dx * dx));
+        k = fma(pow(r, 2), a2, pow(r, 4) * a4);
+      }
       float kf = (float)k;
       mask[(size_t)x * height + y] = kf; /* at<float>(x, y): row x, col y */
       if (kf > mx) mx = kf;
@@ -1033,6 +1065,10 @@ static inline void hsv2bgr_px(const uint8_t* s, uint8_t* d) {
     tab[1] = v * (1.f - sa);
     tab[2] = v * (1.f - sa * h);
     tab[3] = v * (1.f - sa * (1.f - h));
+    if (g_fp_contract) { /* 1 - s*h and 1 - s*(1 - h) each become one fnma */
+      tab[2] = v * fmaf(-sa, h, 1.f);
+      tab[3] = v * fmaf(-sa, 1.f - h, 1.f);
+    }
     b = tab[sector_data[sector][0]];
     g = tab[sector_data[sector][1]];
     r = tab[sector_data[sector][2]];

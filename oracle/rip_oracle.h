@@ -39,6 +39,11 @@ enum {
 };
 
 /* Returns the pattern id for "bayer_xxxx8", -1 for anything else. */
+/* Floating-point contraction model of the float stages (colour matrix, pca map, HSV inverse, vignetting mask plane):
+ * 0 = none (default; what the HIP kernels implement), 1 = fused as GCC / Clang contract the source expressions on FMA
+ * targets, 2 = the other association of the 3-term dot product.  Process-wide; see rip_oracle.c. */
+void ripo_set_fp_contraction(int mode);
+int ripo_get_fp_contraction(void);
 int ripo_bayer_pattern(const char* encoding);
 
 /* cv::demosaicing(COLOR_BayerXX2BGR) + cvtColor(RGB2BGR): net true-colour bilinear

@@ -647,29 +647,44 @@ __global__ __launch_bounds__(256) void ccc_argmax_kernel(CccParams p) {
 
 }  // namespace
 
-void launch_ccc_estimate(const CccParams& p, hipStream_t stream) {
-  if (p.n_frames <= 0) return;
-  // RIP_CCC_LDS_HIST_MIN: smallest batch that takes the LDS histogram (one workgroup = one CU per frame)
-  const int lds_min = tune_int("RIP_CCC_LDS_HIST_MIN", 48);
-  if (p.n_frames >= lds_min) {
-    constexpr unsigned lds = kHistWords * sizeof(unsigned) + sizeof(CccSampleTabs);
-    // the opt-in above 64 KB of dynamic LDS is per device: a process that drives several GPUs (CameraRig) needs it on each
-    static std::atomic<unsigned long long> opted_in{0};
+bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t stream) {
+  if (p.n_frames <= 0) return true;
+  // Batches of at least tn.ccc_lds_hist_min frames take the LDS histogram (one workgroup = one CU per frame).  It needs
+  // ~135 KB of dynamic LDS, an opt-in above 64 KB that is per device (a process that drives several GPUs needs it on each);
+  // where the runtime refuses it the global-atomic kernel -- which runs on any device -- takes over.
+  bool lds_hist = p.n_frames >= tn.ccc_lds_hist_min;
+  constexpr unsigned lds = kHistWords * sizeof(unsigned) + sizeof(CccSampleTabs);
+  if (lds_hist) {
+    static std::atomic<unsigned long long> opted_in{0}, refused{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
-    if (!(opted_in.load(std::memory_order_relaxed) & bit) &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(ccc_hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-      opted_in.fetch_or(bit, std::memory_order_relaxed);
+    if (refused.load(std::memory_order_relaxed) & bit) {
+      lds_hist = false;
+    } else if (!(opted_in.load(std::memory_order_relaxed) & bit)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(ccc_hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+        opted_in.fetch_or(bit, std::memory_order_relaxed);
+      } else {
+        (void)hipGetLastError();  // the refusal is handled here; it must not surface as the batch's launch error
+        refused.fetch_or(bit, std::memory_order_relaxed);
+        lds_hist = false;
+      }
+    }
+  }
+  if (lds_hist) {
     hipLaunchKernelGGL(ccc_hist_lds_kernel, dim3(p.n_frames), dim3(kHistLdsThreads), lds, stream, p);
   } else {
-    (void)hipMemsetAsync(p.hist_counts, 0, (size_t)p.n_frames * 65536 * sizeof(unsigned), stream);
+    if (hipMemsetAsync(p.hist_counts, 0, (size_t)p.n_frames * 65536 * sizeof(unsigned), stream) != hipSuccess) return false;
     hipLaunchKernelGGL(ccc_hist_kernel, dim3(kHistBlocks, p.n_frames), dim3(kBlock), 0, stream, p);
   }
+  // a histogram that was not launched leaves stale counts behind: stop before anything consumes them (the caller must
+  // not advance the Kalman state either)
+  if (hipGetLastError() != hipSuccess) return false;
   hipLaunchKernelGGL(ccc_fft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(ccc_fft_cols_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(ccc_ifft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(ccc_argmax_kernel, dim3(p.n_frames), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess;
 }
 
 }  // namespace rip

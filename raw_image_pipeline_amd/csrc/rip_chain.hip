@@ -129,41 +129,32 @@ struct FastTabs {
       }
   }
 };
-// workgroup size of the fast kernel: the Lab tables are 41 KB, so the vignetting variants share them among
+// workgroup size of the fast kernel: the Lab tables are 33 KB, so the vignetting variants share them among
 // 8 waves (3 workgroups = 24 waves per CU); the others keep 256 threads
-#ifndef RIP_VIG_THREADS
-#define RIP_VIG_THREADS 512
-#endif
-#ifndef RIP_VIG_WPE
-#define RIP_VIG_WPE 6  // waves per SIMD the register allocation must allow: 3 workgroups of 512 threads per CU
-#endif
+constexpr int kVigThreads = 512;
+constexpr int kVigWavesPerSimd = 6;  // waves per SIMD the register allocation must allow: 3 workgroups of 512 threads per CU
 template <int BITS>
 constexpr int fast_threads() {
-  return (BITS & ST_VIG) ? RIP_VIG_THREADS : 256;
+  return (BITS & ST_VIG) ? kVigThreads : 256;
 }
 template <int BITS>
 constexpr int fast_waves_per_simd() {
-  return (BITS & ST_VIG) ? RIP_VIG_WPE : 1;
+  return (BITS & ST_VIG) ? kVigWavesPerSimd : 1;
 }
 
 // The per-pixel stages after the demosaic for the four pixels of one row.
 template <int BITS, int WB>
-__device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const VigRegs& vr,
-                                           const CcRegs& cc, const HsvRegs& hr, const float (&mask)[4], int (&q)[4][3]) {
+__device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const CcRegs& cc,
+                                           const HsvRegs& hr, const float (&mask)[4], int (&q)[4][3]) {
 #pragma unroll
   for (int k = 0; k < 4; k++) apply_wb(WB, w, q[k][0], q[k][1], q[k][2]);
   if constexpr ((BITS & ST_CC) != 0) {
-#if RIP_PK
-    apply_cc2(p, cc, q[0], q[1]);
-    apply_cc2(p, cc, q[2], q[3]);
-#else
 #pragma unroll
     for (int k = 0; k < 4; k++) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
-#endif
   }
   if constexpr ((BITS & ST_VIG) != 0) {
 #pragma unroll
-    for (int k0 = 0; k0 < 4; k0 += RIP_VIG_GROUP) vignette_n<RIP_VIG_GROUP>(tb.vig.v, vr, mask + k0, q + k0);  // gamma folded into VigTabs::lin by the host
+    for (int k0 = 0; k0 < 4; k0 += kVigGroup) vignette_n<kVigGroup>(tb.vig.v, mask + k0, q + k0);  // gamma folded into VigTabs::lin by the host
   } else if constexpr ((BITS & ST_GAMMA) != 0) {
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -188,8 +179,6 @@ template <int BITS, int WB, int NT>
 __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
   __shared__ FastTabs<BITS> tb;
   tb.template load<NT>(p.tabs);
-  VigRegs vr = {};
-  if constexpr ((BITS & ST_VIG) != 0) vr.load();
   CcRegs cc = {};
   if constexpr ((BITS & ST_CC) != 0) cc.load(p);
   HsvRegs hr = {};
@@ -208,6 +197,7 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
   const int per_xcd = (chunks_per_frame + 7) / 8;
   const int xcd = blockIdx.x & 7;
   const bool flip180 = p.flip_angle == 180;
+  const bool dst_nt = p.dst_streaming != 0;
   for (int ci = blockIdx.x >> 3; ci < per_xcd; ci += gridDim.x >> 3) {
     const int chunk = xcd * per_xcd + ci;
     if (chunk >= chunks_per_frame) break;
@@ -273,7 +263,7 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
         if (need_raw) interleave4(v, raw.a, raw.b, raw.c);
         if (has_tap) store12(tap, tap_off[ly], raw);
         if (BITS == 0 && WB == WB_NONE) {
-          store12(dst, dst_off[ly], raw);  // pure demosaic: no per-pixel stage
+          store12(dst, dst_off[ly], raw, dst_nt);  // pure demosaic: no per-pixel stage
           continue;
         }
         if (WB == WB_Q8) {  // grey-world gains on the packed bytes, two pixels per multiply
@@ -288,16 +278,8 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
           q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
           q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
         }
-        pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, vr, cc, hr, mask[ly], q);
-#ifdef RIP_EXP_EXTRA  // experiment: extra independent full-rate VALU work per row (is the kernel VALU-issue bound?)
-        {
-          unsigned dummy = (unsigned)q[0][0];
-#pragma unroll
-          for (int e = 0; e < RIP_EXP_EXTRA; e++) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(dummy));
-          asm volatile("" ::"v"(dummy));
-        }
-#endif
-        store12(dst, dst_off[ly], pack4(q));
+        pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, cc, hr, mask[ly], q);
+        store12(dst, dst_off[ly], pack4(q), dst_nt);
       }
     }
   }
@@ -470,9 +452,9 @@ __global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int ti
 
 
 template <int BITS, int WB>
-void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
+void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream, bool debug_occupancy) {
   constexpr int NT = fast_threads<BITS>();
-  if (std::getenv("RIP_DEBUG_OCC")) {  // development aid: resident workgroups per CU the runtime computes for this variant
+  if (debug_occupancy) {  // development aid: resident workgroups per CU the runtime computes for this variant
     int nb = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_fast_kernel<BITS, WB, NT>, NT, 0);
     hipFuncAttributes fa;
@@ -484,13 +466,13 @@ void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, 
 }
 
 template <int BITS>
-void launch_fast_wb(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
+void launch_fast_wb(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream, bool occ) {
   switch (p.wb_mode) {
-    case WB_Q8: launch_fast<BITS, WB_Q8>(p, im, items, grid, stream); break;
-    case WB_FLOAT: launch_fast<BITS, WB_FLOAT>(p, im, items, grid, stream); break;
-    case WB_PCA: launch_fast<BITS, WB_PCA>(p, im, items, grid, stream); break;
-    case WB_SIMPLE: launch_fast<BITS, WB_SIMPLE>(p, im, items, grid, stream); break;
-    default: launch_fast<BITS, WB_NONE>(p, im, items, grid, stream); break;
+    case WB_Q8: launch_fast<BITS, WB_Q8>(p, im, items, grid, stream, occ); break;
+    case WB_FLOAT: launch_fast<BITS, WB_FLOAT>(p, im, items, grid, stream, occ); break;
+    case WB_PCA: launch_fast<BITS, WB_PCA>(p, im, items, grid, stream, occ); break;
+    case WB_SIMPLE: launch_fast<BITS, WB_SIMPLE>(p, im, items, grid, stream, occ); break;
+    default: launch_fast<BITS, WB_NONE>(p, im, items, grid, stream, occ); break;
   }
 }
 
@@ -531,9 +513,9 @@ bool chain_uses_rot_path(const ChainParams& p) {
 // (FP64 vignetting mask, addresses).  The cheap stage sets (no Lab / HSV round trip) are HBM-bound and stream best one
 // frame at a time -- a frame is contiguous, the next frame of the batch is megabytes away (config5, debayer only:
 // 2.00 ms at 16 frames per visit, 1.65 ms at 1 = 5.1 TB/s).
-static int frame_groups(const ChainParams& p, int cap, int blocks) {
+static int frame_groups(const ChainParams& p, const Tunables& tn, int cap, int blocks) {
   const bool valu_bound = (p.stage_bits & (ST_VIG | ST_HSV)) != 0;
-  const int frames_per_visit = std::max(1, tune_int("RIP_CHAIN_FRAMES", valu_bound ? 16 : 1));
+  const int frames_per_visit = tn.chain_frames > 0 ? tn.chain_frames : (valu_bound ? 16 : 1);
   const int groups = std::max(cap / std::max(blocks, 1), (p.n_frames + frames_per_visit - 1) / frames_per_visit);
   return std::max(1, std::min(p.n_frames, groups));
 }
@@ -544,14 +526,14 @@ void launch_debayer16(const Debayer16Params& p, hipStream_t stream) {
   hipLaunchKernelGGL(debayer16_kernel, dim3(grid_blocks_for(npix, 4096), p.n_frames), dim3(kBlock), 0, stream, p);
 }
 
-void launch_chain(const ChainParams& p, hipStream_t stream) {
+void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream) {
   if (p.n_frames <= 0) return;
   if (chain_uses_rot_path(p)) {
     const int tiles_x = (p.cols / 4 + 3) / 4, tiles_y = (p.rows / 2 + 63) / 64;
     const int tiles = tiles_x * tiles_y;
-    const int cap = tune_grid("RIP_CHAIN_BLOCKS", 2048);
+    const int cap = grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : 2048);
     const int blocks = std::min(cap, tiles);
-    const int groups = frame_groups(p, cap, blocks);
+    const int groups = frame_groups(p, tn, cap, blocks);
     hipLaunchKernelGGL(chain_rot_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, tiles_x, tiles);
     return;
   }
@@ -563,11 +545,11 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     // persistent grid: at most 256 CUs x 8 x 256 threads, a multiple of 8 workgroups (one share per XCD; the kernel
     // strides its chunk loop by gridDim.x / 8)
     // (the 512-thread vignetting variants run ~3 % faster with one chunk per workgroup than with a 768-workgroup persistent grid)
-    const int cap = std::max(8, tune_grid("RIP_CHAIN_BLOCKS", nt == kBlock ? 2048 : 4096) * kBlock / nt / 8 * 8);
+    const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : (nt == kBlock ? 2048 : 4096)) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
-    dim3 grid(blocks, frame_groups(p, cap, blocks));
+    dim3 grid(blocks, frame_groups(p, tn, cap, blocks));
     switch (p.stage_bits & 15) {
-#define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream); break;
+#define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream, tn.debug_occupancy != 0); break;
       RIP_CASE(0) RIP_CASE(1) RIP_CASE(2) RIP_CASE(3) RIP_CASE(4) RIP_CASE(5) RIP_CASE(6) RIP_CASE(7)
       RIP_CASE(8) RIP_CASE(9) RIP_CASE(10) RIP_CASE(11) RIP_CASE(12) RIP_CASE(13) RIP_CASE(14) RIP_CASE(15)
 #undef RIP_CASE
@@ -579,7 +561,7 @@ void launch_chain(const ChainParams& p, hipStream_t stream) {
     const int items = p.rows * (p.cols / 4);
     const int chunks = (items + kBlock - 1) / kBlock;
     const int blocks = std::min(2048, chunks);
-    const int groups = frame_groups(p, 2048, blocks);
+    const int groups = frame_groups(p, tn, 2048, blocks);
     hipLaunchKernelGGL(chain_color_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, im, items);
     return;
   }

@@ -27,11 +27,6 @@ namespace rip {
 namespace {
 
 constexpr int kBlock = 256;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifndef RIP_PK
-#define RIP_PK 0  // 1: packed fp32 (v_pk_mul/add/fma_f32, two pixels per instruction) in the colour matrix and the Lab forward
-                  // transform -- bit-identical, 8 % fewer VALU instructions, but 6 % slower (measured): kept for A/B runs only
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // scalar helpers
@@ -270,29 +265,6 @@ __device__ __forceinline__ void apply_cc(const ChainParams& p, const CcRegs& cc,
   g = sat_round_u8(o[1]);
   r = sat_round_u8(o[2]);
 }
-// two pixels at once on packed fp32 (v_pk_mul_f32 / v_pk_add_f32): the same separate multiplies and adds per element
-__device__ __forceinline__ void apply_cc2(const ChainParams& p, const CcRegs& cc, int (&q0)[3], int (&q1)[3]) {
-  const f32x2 fb = {(float)q0[0], (float)q1[0]}, fg = {(float)q0[1], (float)q1[1]}, fr = {(float)q0[2], (float)q1[2]};
-  f32x2 o[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const f32x2 m0 = cc.m[c * 3], m1 = cc.m[c * 3 + 1], m2 = cc.m[c * 3 + 2];
-    o[c] = fb * m0 + fg * m1 + fr * m2;
-  }
-  if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
-    keep_branch();
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const f32x2 bias = p.cc_bias[c];
-      o[c] = o[c] + bias;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    q0[c] = sat_round_u8(o[c][0]);
-    q1[c] = sat_round_u8(o[c][1]);
-  }
-}
 __device__ __forceinline__ void apply_cc(const ChainParams& p, int& b, int& g, int& r) {
   float fb = (float)b, fg = (float)g, fr = (float)r;
   float o[3];
@@ -402,10 +374,10 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
 //    wave64), an SGPR source makes the same opcode cost 4.3 -- profiles/r02_valu_issue_rates.txt.  The same
 //    product as three v_mfma_f32_4x4x1_16B_f32 per pixel (each lane's own scalar times the four coefficients its
 //    4-lane block holds) was measured too: bit-identical, but 8.4 cycles per MFMA and no overlap with the VALU
-//    issue of the other waves, i.e. slower than the FMAs it replaces (RIP_LAB_MFMA=1 keeps it for A/B runs).
+//    issue of the other waves, i.e. slower than the FMAs it replaces (that variant, the packed-fp32 one and the extra-VALU probe are in the history at 84c88d7; they are not part of the library).
 //  * LabCbrtTab_b re-tabulated as three float tables whose entries already carry the factors and
 //    tie-breaking offsets of the L / a / b formulas: X -> 25 f + 1/8, Y -> {L, 25 f}, Z -> 25 f - 1/8 (or the X table
-//    again and + 1/4 after the subtraction: RIP_VIG_SHARED_XZ), so
+//    again and + 1/4 after the subtraction: 8 KB less LDS), so
 //    a = RN((X - Y) * 5 / 8192) + 128 and b = RN((Y - Z) / 4096) + 128 exactly (the +-1/8 turns CV_DESCALE's
 //    round-half-up into a never-tying round-to-nearest; every table index stays <= 2040 because each
 //    forward row sums to 4096).
@@ -414,7 +386,6 @@ __device__ __forceinline__ void apply_vignette(const ChainParams& p, const Tabs&
 //    channel, whose two products are the x and z terms (z is biased by kZoff to fit 16 bits; the bias is
 //    pre-multiplied into r).  Ranges (all 2^24 inputs x every L'): tests/test_oracle_known_answers.py.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 // RGB2Lab_b coefficients (B, G, R columns of the X, Y, Z rows) and Lab2RGBinteger coefficients (X, Y, Z columns of
 // the B, G, R rows), lab_shift = 12: compile-time so that they reach the instructions as literals.
 // rip_api.cpp checks them against the host-built tables (make_color_tables) when a handle is created.
@@ -422,19 +393,11 @@ constexpr int kLabFwd[9] = {778, 1541, 1777, 296, 2929, 871, 3575, 448, 73};
 constexpr int kLabInv[9] = {217, -836, 4715, -3773, 7684, 185, 12615, -6296, -2223};
 constexpr int kVigCbrtN = 2048;  // LabCbrtTab_b indices reachable from 8-bit input: 0 .. 2040
 constexpr int kZoff = 27500;     // z in [-999, 59828] -> z - kZoff fits int16
-#ifndef RIP_VIG_SHARED_XZ
-#define RIP_VIG_SHARED_XZ 1  // one 25 f + 1/8 table for the X and the Z lookup (the Z side adds 1/4 after the subtraction): 8 KB less LDS
-#endif
-#ifndef RIP_VIG_GROUP
-#define RIP_VIG_GROUP 4      // pixels of a row taken through the round trip together (ILP against live registers)
-#endif
+constexpr int kVigGroup = 4;     // pixels of a row taken through the round trip together (ILP against live registers)
 struct VigTabs {
   float lin[256];
   float cbx[kVigCbrtN];
   float2 cby[kVigCbrtN];
-#if !RIP_VIG_SHARED_XZ
-  float cbz[kVigCbrtN];
-#endif
   int4 yf[256];
   uint8_t invg[4096];
   template <int NT>
@@ -459,116 +422,43 @@ struct VigTabs {
       const int L = clampi((296 * f - 1336934 + (1 << 14)) >> 15, 0, 255);
       cbx[i] = f25 + 0.125f;
       cby[i] = make_float2((float)L, f25);
-#if !RIP_VIG_SHARED_XZ
-      cbz[i] = f25 - 0.125f;
-#endif
     }
     uint32_t* d = reinterpret_cast<uint32_t*>(invg);
     const uint32_t* s = reinterpret_cast<const uint32_t*>(t->inv_gamma);
     for (int i = threadIdx.x; i < 1024; i += NT) d[i] = s[i];
   }
 };
-// per-lane constants of the round trip
-#ifndef RIP_LAB_MFMA
-#define RIP_LAB_MFMA 0
-#endif
-
-struct VigRegs {
-#if RIP_LAB_MFMA
-  float a0, a1, a2;  // MFMA A operands: lane l holds kLabFwd[(l & 3) * 3 + c] / 4096 (row 3: 0)
-#endif
-  __device__ __forceinline__ void load() {
-#if RIP_LAB_MFMA
-    const int row = (int)(threadIdx.x & 3u);
-    a0 = row == 0 ? kLabFwd[0] / 4096.0f : row == 1 ? kLabFwd[3] / 4096.0f : row == 2 ? kLabFwd[6] / 4096.0f : 0.0f;
-    a1 = row == 0 ? kLabFwd[1] / 4096.0f : row == 1 ? kLabFwd[4] / 4096.0f : row == 2 ? kLabFwd[7] / 4096.0f : 0.0f;
-    a2 = row == 0 ? kLabFwd[2] / 4096.0f : row == 1 ? kLabFwd[5] / 4096.0f : row == 2 ? kLabFwd[8] / 4096.0f : 0.0f;
-#endif
-  }
-};
-
 // Four pixels of one row through BGR -> Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93).
 template <int N>
-__device__ __forceinline__ void vignette_n(const VigTabs& tb, const VigRegs& vr, const float* mask, int (*q)[3]) {
+__device__ __forceinline__ void vignette_n(const VigTabs& tb, const float* mask, int (*q)[3]) {
   constexpr float kMagic = 12582912.0f;         // 1.5 * 2^23: ulp 1 in [2^23, 2^24)
   constexpr unsigned kMagicBits = 0x4B400000u;  // its bit pattern
   unsigned ix[N], iy[N], iz[N];
-#if RIP_PK
-  // Two pixels per instruction in the fp32 part: v_pk_fma_f32 / v_pk_add_f32 on register pairs (same arithmetic per
-  // element, half the instructions; slower in practice, see RIP_PK).
-  static_assert(N % 2 == 0 || N == 1, "pairs");
-#pragma unroll
-  for (int k = 0; k + 1 < N; k += 2) {
-    const f32x2 v0 = {tb.lin[q[k][0]], tb.lin[q[k + 1][0]]}, v1 = {tb.lin[q[k][1]], tb.lin[q[k + 1][1]]},
-                v2 = {tb.lin[q[k][2]], tb.lin[q[k + 1][2]]};
-    f32x2 acc[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const f32x2 c0 = (float)kLabFwd[r * 3] * (1.0f / 4096.0f), c1 = (float)kLabFwd[r * 3 + 1] * (1.0f / 4096.0f),
-                  c2 = (float)kLabFwd[r * 3 + 2] * (1.0f / 4096.0f), half = 1.0f / 8192.0f;
-      acc[r] = __builtin_elementwise_fma(v2, c2, __builtin_elementwise_fma(v1, c1, __builtin_elementwise_fma(v0, c0, half)));
-      acc[r] = acc[r] + kMagic;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      ix[k + j] = __float_as_uint(acc[0][j]) - kMagicBits;
-      iy[k + j] = __float_as_uint(acc[1][j]) - kMagicBits;
-      iz[k + j] = __float_as_uint(acc[2][j]) - kMagicBits;
-    }
-  }
-  if (N == 1) {
-    const float v0 = tb.lin[q[0][0]], v1 = tb.lin[q[0][1]], v2 = tb.lin[q[0][2]];
-    float acc[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-      acc[r] = __builtin_fmaf(v2, (float)kLabFwd[r * 3 + 2] * (1.0f / 4096.0f),
-                              __builtin_fmaf(v1, (float)kLabFwd[r * 3 + 1] * (1.0f / 4096.0f),
-                                             __builtin_fmaf(v0, (float)kLabFwd[r * 3] * (1.0f / 4096.0f), 1.0f / 8192.0f)));
-    ix[0] = __float_as_uint(acc[0] + kMagic) - kMagicBits;
-    iy[0] = __float_as_uint(acc[1] + kMagic) - kMagicBits;
-    iz[0] = __float_as_uint(acc[2] + kMagic) - kMagicBits;
-  }
-#else
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const float v0 = tb.lin[q[k][0]], v1 = tb.lin[q[k][1]], v2 = tb.lin[q[k][2]];
     // acc_r = (C_r . v + 0.5) / 4096, exact; RN(acc_r + magic) = (C_r . v + 2048) >> 12 (never a tie)
-    f32x4 acc = {1.0f / 8192.0f, 1.0f / 8192.0f, 1.0f / 8192.0f, 0.0f};
-#if RIP_LAB_MFMA
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vr.a0, v0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vr.a1, v1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(vr.a2, v2, acc, 0, 0, 0);
-#else
+    float acc[3] = {1.0f / 8192.0f, 1.0f / 8192.0f, 1.0f / 8192.0f};
 #pragma unroll
     for (int r = 0; r < 3; r++)
       acc[r] = __builtin_fmaf(v2, (float)kLabFwd[r * 3 + 2] * (1.0f / 4096.0f),
                               __builtin_fmaf(v1, (float)kLabFwd[r * 3 + 1] * (1.0f / 4096.0f),
                                              __builtin_fmaf(v0, (float)kLabFwd[r * 3] * (1.0f / 4096.0f), acc[r])));
-#endif
     ix[k] = __float_as_uint(acc[0] + kMagic) - kMagicBits;
     iy[k] = __float_as_uint(acc[1] + kMagic) - kMagicBits;
     iz[k] = __float_as_uint(acc[2] + kMagic) - kMagicBits;
   }
-#endif
   int fx[N], fz[N], x[N], z[N];
   int4 e[N];
 #pragma unroll
   for (int k = 0; k < N; k++) {
-#if RIP_VIG_SHARED_XZ
     const float X = tb.cbx[ix[k]], Zt = tb.cbx[iz[k]];
-#else
-    const float X = tb.cbx[ix[k]], Z = tb.cbz[iz[k]];
-#endif
     const float2 LY = tb.cby[iy[k]];
     const int L = sat_round_u8(LY.x * mask[k]);  // convertTo(32F), multiply, convertTo(8U)
     // a, b never leave [0, 255] (exhaustive test), so saturate_cast is dead; abits = kMagicBits + a
     const unsigned abits = __float_as_uint(__builtin_fmaf(X - LY.y, 5.0f / 8192.0f, kMagic + 128.0f));
-#if RIP_VIG_SHARED_XZ
     // 25 fY - (25 fZ + 1/8) + 1/4 = 25 (fY - fZ) + 1/8, exact (multiples of 1/8 below 2^20)
     const unsigned bbits = __float_as_uint(__builtin_fmaf((LY.y - Zt) + 0.25f, 1.0f / 4096.0f, kMagic + 128.0f));
-#else
-    const unsigned bbits = __float_as_uint(__builtin_fmaf(LY.y - Z, 1.0f / 4096.0f, kMagic + 128.0f));
-#endif
     e[k] = tb.yf[L];
     // adiv = ((5 * a * 53687 + 128) >> 13) - 128 * BASE / 500, bdiv = ((b * 41943 + 16) >> 9) - 128 * BASE / 200 + 1:
     // the 24-bit multiply reads 0x400000 + a; the constant takes 0x400000 * K back and carries the subtrahend
@@ -603,6 +493,8 @@ __device__ __forceinline__ void vignette_n(const VigTabs& tb, const VigRegs& vr,
     const int bo = __builtin_amdgcn_sdot2(xz, cb, e[k].y, false) >> 14;
     const int go = __builtin_amdgcn_sdot2(xz, cg, e[k].z, false) >> 14;
     const int ro = __builtin_amdgcn_sdot2(xz, cr, e[k].w, false) >> 14;
+    // (the 4 KB sRGBInvGammaTab_b served by buffer_load_ubyte gathers from L1 instead of LDS: 2.43 -> 3.07 ms per 256
+    // frames, round 3 -- a wave's 64 scattered bytes cost the texture path more than the LDS bank conflicts they avoid)
     q[k][0] = tb.invg[clampi(bo, 0, 4095)];
     q[k][1] = tb.invg[clampi(go, 0, 4095)];
     q[k][2] = tb.invg[clampi(ro, 0, 4095)];
@@ -927,6 +819,16 @@ __device__ __forceinline__ void store12(__amdgpu_buffer_rsrc_t frame, unsigned o
   u32x3 u = {v.a, v.b, v.c};
   __builtin_amdgcn_raw_buffer_store_b96(u, frame, (int)off, 0, 0);
 }
+// `nt` (wave-uniform): non-temporal store for an image no kernel of this batch reads again (aux bit 1 = nt on gfx950)
+__device__ __forceinline__ void store12(__amdgpu_buffer_rsrc_t frame, unsigned off, const Pack3& v, bool nt) {
+  u32x3 u = {v.a, v.b, v.c};
+  if (nt) {
+    keep_branch();
+    __builtin_amdgcn_raw_buffer_store_b96(u, frame, (int)off, 0, 2);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b96(u, frame, (int)off, 0, 0);
+  }
+}
 
 // Grey-world applyChannelGains (x * q) >> 8 on four packed bytes.  q <= 256 (the gains are normalised
 // by the largest one), so the products of the even and of the odd bytes stay inside their 16-bit
@@ -994,16 +896,8 @@ bool bayer_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, i
          (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
 }
 
-// launch tunables, overridable from the environment for experiments.  tune_grid: persistent workgroups per launch,
-// always a multiple of 8 and at least 8 (the kernels give every XCD its own share and stride by gridDim.x / 8);
-// tune_int: any other positive integer (frames per visit, ring stages, workgroups per CU).
-int tune_int(const char* name, int dflt) {
-  const char* e = std::getenv(name);
-  if (!e || !*e) return dflt;
-  const int v = std::atoi(e);
-  return v > 0 ? v : dflt;
-}
-int tune_grid(const char* name, int dflt) { return std::max(8, tune_int(name, dflt) / 8 * 8); }
+// persistent grids are a multiple of 8 workgroups and at least 8: the kernels give every XCD its own share and stride by gridDim.x / 8
+int grid_multiple_of_8(int blocks) { return std::max(8, blocks / 8 * 8); }
 
 }  // namespace
 }  // namespace rip

@@ -74,6 +74,9 @@ struct ChainParams {
   size_t dst_step, dst_frame_stride;
   int drows, dcols;
   int channels;  // 3, or 1 for mono pass-through
+  // dst is the batch's final image and no kernel of this batch reads it again: the fast kernel stores it non-temporally
+  // (+1.7 % on the chain without a remap behind it; with the remap gathering from dst the same stores cost the remap 19 %)
+  int dst_streaming;
   // optional post-flip, pre-WB tap (tightly packed rows), may be null
   uint8_t* tap;
   size_t tap_frame_stride;
@@ -176,13 +179,32 @@ struct FisheyeMapParams {
 void launch_fisheye_maps(const FisheyeMapParams& p, hipStream_t stream);
 void launch_atan_probe(const double* in, double* out, int n, hipStream_t stream);  // test hook: the kernel's atan
 
+// Launch tunables.  The defaults are the measured optima; the environment variables named beside them
+// override them for experiments, and are read ONCE, by tunables_from_env() when a handle is created -- never on a launch path.
+struct Tunables {
+  int chain_blocks = 0;       // RIP_CHAIN_BLOCKS: persistent 256-thread workgroups per launch; 0 = 2048 (4096 for the 512-thread variants)
+  int chain_frames = 0;       // RIP_CHAIN_FRAMES: frames per item visit; 0 = 16 for the VALU-bound stage sets, 1 for the HBM-bound ones
+  int stats_blocks = 2048;    // RIP_STATS_BLOCKS
+  int remap_ring = 1;         // RIP_REMAP_RING=0: register-pipelined tiled kernel instead of the LDS-DMA ring
+  int remap_stages = 3;       // RIP_REMAP_STAGES: LDS ring size
+  int remap_per_cu = 0;       // RIP_REMAP_PER_CU: resident workgroups per CU; 0 = 6 (ring) / 8 (tiled)
+  int remap_frames = 4;       // RIP_REMAP_FRAMES: frames per tile visit
+  int ccc_lds_hist_min = 48;  // RIP_CCC_LDS_HIST_MIN: smallest batch that takes the LDS histogram
+  int overlap_groups = 0;     // RIP_OVERLAP_GROUPS: frame groups a batch is split into on the handle's internal streams (rip_api.cpp run_batch); 0 / 1 = off (the measured optimum)
+  int overlap_mode = 1;       // RIP_OVERLAP_MODE: 1 = remap(g) beside stats(g+1) + chain(g+1); 2 = beside stats(g+1) only (the chain waits)
+  int debug_occupancy = 0;    // RIP_DEBUG_OCC: print the residency of every chain variant launched (development aid)
+};
+Tunables tunables_from_env();  // rip_api.cpp; called by rip_create
+
 // ---- launchers (asynchronous on `stream`) -------------------------------------------------------
 // Returns false (and launches nothing) when the geometry does not qualify for the tiled kernel.
-bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream);
-void launch_chain(const ChainParams& p, hipStream_t stream);
+bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream);
+void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream);
 void launch_debayer16(const Debayer16Params& p, hipStream_t stream);
-void launch_stats(const StatsParams& p, hipStream_t stream);
-void launch_ccc_estimate(const CccParams& p, hipStream_t stream);
+void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream);
+// Returns false when the histogram launch failed: nothing after it was enqueued and the caller must not run the
+// state-advancing finalisation on stale data.
+bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t stream);
 // Turns raw statistics into FrameWb (grey-world / pca) or runs the ccc temporal filter + gains.
 void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
                         const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream,

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kBlock) void remap_generic_kernel(RemapParams p) {
 
 }  // namespace
 
-bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
+bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream) {
   const RemapParams& b = p.base;
   if (b.n_frames <= 0) return true;
   const bool ok = b.channels == 3 && b.dcols % 4 == 0 && b.dst_step % 4 == 0 && b.dst_frame_stride % 4 == 0 && aligned4(b.dst) &&
@@ -470,17 +470,17 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
   RemapTiledParams q = p;
   q.lds_bytes = (std::max(p.lds_bytes, 16u) + 15u) & ~15u;
   const unsigned chunks = q.lds_bytes / 16u;  // upper bound of the 16-byte chunks of any tile
-  const int ring_env = std::getenv("RIP_REMAP_RING") ? std::atoi(std::getenv("RIP_REMAP_RING")) : 1;
+  const int ring_env = tn.remap_ring;
   // measured on config2 (sweeps in DESIGN.md): 3 stages (two frames ahead) with 4 workgroups per CU; more resident
   // workgroups fetch more (the source rectangles of neighbouring tiles stop meeting in L2) and run slower
-  const int stages_env = tune_int("RIP_REMAP_STAGES", 3);
+  const int stages_env = tn.remap_stages;
   if (ring_env && chunks <= 4u * kRemapTileThreads) {
     // LDS-DMA ring: PRE chunks per lane and frame, `stages` buffers of PRE * 4 KiB
     const int pre = chunks <= 1u * kRemapTileThreads ? 1 : (chunks <= 2u * kRemapTileThreads ? 2 : 4);
     const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
     q.stages = std::max(2, std::min(4, stages_env));
     const unsigned lds = (unsigned)q.stages * stage_bytes + 16u;  // the three-dword tap reads run up to 11 B past a row
-    const int per_cu = std::max(1, std::min(tune_int("RIP_REMAP_PER_CU", 6), (int)((160u * 1024u) / (lds + 256u))));
+    const int per_cu = std::max(1, std::min(tn.remap_per_cu > 0 ? tn.remap_per_cu : 6, (int)((160u * 1024u) / (lds + 256u))));
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
     blocks = std::max(8, blocks / 8 * 8);
     // blockIdx.y splits the batch into groups of frames: enough groups to fill the chip when there are few tiles,
@@ -488,7 +488,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
     // same few source frames (60 MB at 2448x2048: L2 / Infinity Cache resident, so the overlapping rectangles of
     // neighbouring tiles are fetched once) and the dispatcher balances 16x more, smaller units.  Measured on
     // config2, 64 frames: 64 frames per visit 0.61 ms, 8: 0.57, 4: 0.54, 2: 0.58, 1: 0.71.
-    const int frames_per_visit = std::max(1, tune_int("RIP_REMAP_FRAMES", 4));
+    const int frames_per_visit = std::max(1, tn.remap_frames);
     int groups = std::max((256 * per_cu) / blocks, (b.n_frames + frames_per_visit - 1) / frames_per_visit);
     groups = std::max(1, std::min(b.n_frames, groups));
     const dim3 grid(blocks, groups);
@@ -503,7 +503,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, hipStream_t stream) {
     int pre = !ring_env && b.n_frames >= 2 && chunks <= 2u * kRemapTileThreads ? 2 : 0;
     q.double_buffer = pre > 0 ? 1 : 0;
     const unsigned lds = (q.double_buffer ? 2u * q.lds_bytes : q.lds_bytes) + 16u;
-    const int per_cu = std::max(1, std::min(tune_int("RIP_REMAP_PER_CU", 8), (int)((160u * 1024u) / (lds + 256u))));
+    const int per_cu = std::max(1, std::min(tn.remap_per_cu > 0 ? tn.remap_per_cu : 8, (int)((160u * 1024u) / (lds + 256u))));
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
     blocks = std::max(8, blocks / 8 * 8);
     const int groups = std::max(1, std::min(b.n_frames, (256 * per_cu) / blocks));  // few tiles: split the batch too

@@ -141,7 +141,15 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, int c
   const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
   const unsigned thresh255 = min(p.thresh255, 255u);
   const int lane = threadIdx.x & 63;
-  const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+  // Block b runs on XCD b % 8 (observed dispatch order; speed only): every XCD takes a contiguous range of tasks, so that
+  // neighbouring column strips -- whose 256-byte row segments straddle the same 128-byte lines when the row pitch is not
+  // a multiple of 128 -- and vertically adjacent row ranges (two shared halo rows) meet in one L2.
+#ifdef RIP_X_STATS_NOXCD
+  const int logical_block = (int)blockIdx.x;
+#else
+  const int logical_block = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+#endif
+  const int task = __builtin_amdgcn_readfirstlane(logical_block * (kBlock / 64) + (int)(threadIdx.x >> 6));
   StatAcc a = {};
   if (task < n_tasks) {
     const int cw = task % col_waves, range = task / col_waves;
@@ -317,18 +325,19 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
         FrameWb w = {};
         w.uv_raw[0] = s_raw[i][0];
         w.uv_raw[1] = s_raw[i][1];
-        // computeGains (:342-381) with exp(-L) taken from the host-built table
-        const int ux = clampi(s_flt[i][0], 0, 255), uy = clampi(s_flt[i][1], 0, 255);
-        float gain_r = 1.0f / tabs->exp_neg_tab[ux];
-        float gain_g = 1.0f;
-        float gain_b = 1.0f / tabs->exp_neg_tab[uy];
-        float factor = fminf(fminf(gain_r, gain_g), gain_b);
-        gain_r /= factor;
-        gain_g /= factor;
-        gain_b /= factor;
-        w.fg[0] = gain_b;
-        w.fg[1] = gain_g;
-        w.fg[2] = gain_r;
+        // Illuminant at log-chroma bin (u, v) -> channel gains (Barron 2015, as the reference uses it without the luminance
+        // term): each channel is divided by its attenuation exp(-L) -- green is the anchor, L = 0 -- and the triple is scaled
+        // so that the smallest gain is exactly one.  exp(-L) per bin is a host-built table (DevTables::exp_neg_tab), so no
+        // device transcendental is involved; channel order B, G, R like every FrameWb field.
+        const int bin[3] = {clampi(s_flt[i][1], 0, 255), -1, clampi(s_flt[i][0], 0, 255)};  // B <- v, G anchor, R <- u
+        float smallest = 1.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          w.fg[c] = bin[c] < 0 ? 1.0f : 1.0f / tabs->exp_neg_tab[bin[c]];
+          smallest = fminf(smallest, w.fg[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) w.fg[c] /= smallest;
         w.uv[0] = s_flt[i][0];
         w.uv[1] = s_flt[i][1];
         out[f0 + i] = w;
@@ -423,7 +432,7 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
 
 }  // namespace
 
-void launch_stats(const StatsParams& p, hipStream_t stream) {
+void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream) {
   if (p.n_frames <= 0) return;
   if (bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind)) {
     ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
@@ -435,12 +444,13 @@ void launch_stats(const StatsParams& p, hipStream_t stream) {
     const int col_waves = (groups + 63) / 64;
     // per frame: 512 wave tasks when the batch fills the chip anyway, at most 1024 for a single frame (more
     // tasks only queue up on the three 64-bit atomics every workgroup ends with: 22 -> 12.6 us for one frame)
-    const int budget = tune_grid("RIP_STATS_BLOCKS", 2048) * 4;
+    const int budget = grid_multiple_of_8(tn.stats_blocks) * 4;
     const int target_tasks = std::max(8, std::min(budget / 8, budget / std::max(1, std::min(p.n_frames, 16))));
     int pairs_per_task = std::max(2, (int)(((long long)col_waves * n_pairs + target_tasks - 1) / target_tasks));
     pairs_per_task = std::min((pairs_per_task + 1) & ~1, 128);  // even: the kernel consumes two pairs per iteration
     const int n_tasks = col_waves * ((n_pairs + pairs_per_task - 1) / pairs_per_task);
-    const dim3 grid((n_tasks + kBlock / 64 - 1) / (kBlock / 64), p.n_frames);
+    const int task_blocks = (n_tasks + kBlock / 64 - 1) / (kBlock / 64);
+    const dim3 grid((task_blocks + 7) / 8 * 8, p.n_frames);  // a multiple of 8: one contiguous task range per XCD
     (void)items;
     (void)im;
     if (p.mode == WB_Q8)

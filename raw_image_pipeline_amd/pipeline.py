@@ -164,6 +164,42 @@ class RawImagePipeline:
             image[...] = out
         return out
 
+    # ---- asynchronous host frames (rip_submit / rip_collect; no counterpart in the reference's binding) -------------
+    def submit(self, image, encoding):
+        """Enqueues upload + chain + download of one host frame and returns its ticket without waiting (rip_submit).  Up to
+        ``set_ring_depth`` (default 3) frames may be in flight; frames are processed in submission order."""
+        img = np.asarray(image)
+        if img.dtype not in (np.uint8, np.uint16) or img.ndim not in (2, 3):
+            raise ValueError("image must be uint8 (or uint16 Bayer), HxW or HxWxC")
+        if img.strides[-1] != img.itemsize or (img.ndim == 3 and img.strides[1] != img.shape[2] * img.itemsize):
+            img = np.ascontiguousarray(img)
+        rows, cols = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        t = C.c_uint64()
+        self._call("rip_submit", img.ctypes.data_as(C.c_void_p), rows, cols, cn, C.c_size_t(img.strides[0]), encoding.encode(), C.byref(t))
+        return t.value
+
+    def collect(self, ticket, copy=True):
+        """Waits for the frame of ``ticket`` and returns its image (rip_collect).  ``copy=False`` returns a read-only view of
+        the handle's pinned result buffer instead: valid until ``ring depth`` further frames have been submitted."""
+        r, c, k = C.c_int(), C.c_int(), C.c_int()
+        enc = C.create_string_buffer(32)
+        view = C.c_void_p()
+        self._call("rip_collect", C.c_uint64(int(ticket)), None, C.c_size_t(0), C.byref(view), C.byref(r), C.byref(c), C.byref(k), enc)
+        self.last_encoding = enc.value.decode()
+        wide = self.last_encoding.endswith("16")
+        n = r.value * c.value * k.value
+        buf = (C.c_uint16 if wide else C.c_uint8) * n
+        arr = np.frombuffer(buf.from_address(view.value), np.uint16 if wide else np.uint8)
+        arr = arr.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
+        if copy:
+            return arr.copy()
+        arr.flags.writeable = False
+        return arr
+
+    def set_ring_depth(self, depth):
+        self._call("rip_set_ring_depth", int(depth))
+
     def apply_device(self, frames, encoding, out=None, tap_debayered=None, tap_color=None):
         """Device-resident batch (rip_apply_device).  ``frames``: uint8 CUDA tensor [n, rows, cols]
         or [n, rows, cols, c] (torch) already in HBM; returns the output tensor [n, R, C(, 3)].
@@ -496,6 +532,11 @@ class RawImagePipeline:
         buf = np.empty((n_frames, 8), np.float32)
         self._call("rip_get_white_balance_info", buf.ctypes.data_as(C.c_void_p), int(n_frames))
         return buf
+
+    def set_tunable(self, name, value):
+        """Launch tunable of this handle (rip_set_tunable: development / test hook; the library reads its environment
+        overrides once, when the handle is created)."""
+        self._call("rip_set_tunable", name.encode(), int(value))
 
     KERNEL_CLASSES = ("stats", "ccc", "chain", "remap")
 

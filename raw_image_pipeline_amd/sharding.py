@@ -42,6 +42,29 @@ def sum_over_ranks(value):
     return float(t.item())
 
 
+def gather_over_ranks(value):
+    """Every rank's value, in rank order (all_gather): the per-rank record of the benchmark line."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    mine = _dev(torch.tensor([float(value)], dtype=torch.float64))
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def communicator_census():
+    """What the process group itself reports, plus what a collective over it proves: {"backend", "world_size" (as the
+    communicator reports it), "ranks_counted" (all_reduce SUM of one per rank), "devices" (CUDA ordinal of every rank, -1 on
+    a host backend)} -- so that a multi-GPU benchmark record answers 'did RCCL see N ranks on N devices' by itself."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "ranks_counted": 1, "devices": [torch.cuda.current_device() if torch.cuda.is_available() else -1]}
+    one = _dev(torch.ones(1, dtype=torch.int64))
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_counted": int(one.item()),
+            "devices": [int(v) for v in gather_over_ranks(dev)]}
+
+
 def broadcast_constants(tensor, src=0):
     """Per-camera constants (undistortion maps, LUTs, ccc model spectrum) computed once on `src`."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -87,6 +87,21 @@ int main(int argc, char** argv) {
   Mat tap = proc.getDistDebayeredImage(), col = proc.getDistColorImage(), fin = proc.getProcessedImage();
   if (tap.rows != h || col.rows != h || fin.rows != h || !proc.getRectMask().empty()) return fail("taps");
   if (std::memcmp(fin.data, out.data, (size_t)w * h * 3) != 0) return fail("processed tap");
+  // streaming extension: submit() / collect(): two frames in flight, a view of the pinned result and a copy
+  {
+    const uint64_t t1 = proc.submit(bayer, "bayer_rggb8"), t2 = proc.submit(bayer, "bayer_rggb8");
+    std::string e1, e2;
+    Mat v1 = proc.collectView(t1, e1);
+    if (e1 != "bgr8" || v1.rows != h || v1.cols != w || v1.channels() != 3) return fail("collectView geometry");
+    if (std::memcmp(v1.data, out.data, (size_t)w * h * 3) != 0) return fail("collectView != process");
+    Mat c2 = proc.collect(t2, e2);
+    if (e2 != "bgr8" || std::memcmp(c2.data, out.data, (size_t)w * h * 3) != 0) return fail("collect != process");
+    try {
+      proc.collect(t2, e2);
+      return fail("ticket collected twice");
+    } catch (const std::invalid_argument&) {
+    }
+  }
   try {  // cvtColor(BGR2Lab) on one channel: cv::Exception with OpenCV, AssertionError without
     Mat mono = make_u8(h, w, 1);
     std::memset(mono.data, 7, (size_t)w * h);

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import assert_images_equal, cfg, configure, oracle_run
-from raw_image_pipeline_amd import RipAssertError, synth
+from raw_image_pipeline_amd import RipAssertError, RipError, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -165,8 +165,8 @@ def test_undistortion_batch_through_the_lds_ring(gpu_pipe, oracle, monkeypatch, 
     """The tiled remap streams the frames of a batch through an LDS ring (LDS-DMA, `stages` buffers).  fov_scale
     widens the source rectangle of a tile: 1 chunk per lane (0.6), 2 (1.0), 4 (2.0), then the unpipelined fallback kernel (3.6)."""
     import torch
-    monkeypatch.setenv("RIP_REMAP_STAGES", str(stages))
-    monkeypatch.setenv("RIP_REMAP_RING", str(ring))
+    gpu_pipe.set_tunable("remap_stages", stages)
+    gpu_pipe.set_tunable("remap_ring", ring)
     w, h, n = 448, 272, 7
     c = cfg(undistort=True, cam=synth.camera_model(w, h), fov_scale=fov)
     configure(gpu_pipe, c)
@@ -252,9 +252,9 @@ def test_batch_with_many_frames_per_workgroup(gpu_pipe, oracle, monkeypatch, wb)
     workgroup walk several frames of the batch, as it does at the benchmark's size: each frame must still equal
     the oracle's single-frame result."""
     import torch
-    monkeypatch.setenv("RIP_CHAIN_BLOCKS", "8")
-    monkeypatch.setenv("RIP_STATS_BLOCKS", "8")
-    monkeypatch.setenv("RIP_REMAP_PER_CU", "1")
+    gpu_pipe.set_tunable("chain_blocks", 8)
+    gpu_pipe.set_tunable("stats_blocks", 8)
+    gpu_pipe.set_tunable("remap_per_cu", 1)
     w, h, n = 448, 272, 9
     c = full_chain_cfg(w, h, wb=(wb != "none"), wb_method=wb if wb != "none" else "grey_world", ce=True, ce_sat=1.1)
     configure(gpu_pipe, c)
@@ -417,7 +417,7 @@ def test_ccc_lds_histogram_path(gpu_pipe, oracle, monkeypatch, size, pattern, fl
     dev = torch.from_numpy(frames).cuda()
     outs = {}
     for mode, lds_min in (("lds", "1"), ("atomic", "1000000")):
-        monkeypatch.setenv("RIP_CCC_LDS_HIST_MIN", lds_min)
+        gpu_pipe.set_tunable("ccc_lds_hist_min", int(lds_min))
         outs[mode] = gpu_pipe.apply_device(dev, pattern).cpu().numpy()
         outs[mode + "_uv"] = gpu_pipe.get_white_balance_info(n)[:, 6:8].copy()
     assert np.array_equal(outs["lds"], outs["atomic"]) and np.array_equal(outs["lds_uv"], outs["atomic_uv"])
@@ -610,3 +610,57 @@ def test_debug_stage_dumps_do_not_advance_the_ccc_filter_and_handle_mono(rip_lib
         img = read_png(str(tmp_path / (name + ".png")))
         assert img.ndim == 2
         assert np.array_equal(img, normalize_minmax(ref if k >= 4 else mono).reshape(h, w)), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [1, 3])
+def test_submit_collect_stream_of_32_frames_ccc_temporal(rip_lib, oracle, depth):
+    """The asynchronous host path (rip_submit / rip_collect, what a streaming caller like raw_image_pipeline_ros.cpp:219-288
+    would use): 32 frames of a ccc + temporal-consistency stream with up to `depth` frames in flight.  Every collected frame
+    equals the oracle's, which sees the frames strictly one after the other: the Kalman state advances in submission order
+    whatever overlaps.  Also: the ring refuses a frame too many, tickets can be collected out of order, the taps follow the
+    collected frame, and the zero-copy view holds the same pixels as the copy."""
+    from raw_image_pipeline_amd import RawImagePipeline
+    w, h, n = 384, 240, 32
+    filt, bias = synth.ccc_model()
+    pipe = RawImagePipeline(False, "", "", "", device=0)
+    pipe.set_ccc_model(filt, bias)
+    pipe.set_ccc_kalman_model(1.0, 10.0)
+    occ = oracle.CCC(filt, bias)
+    occ.set_kalman_model(1.0, 10.0)
+    cam = synth.camera_model(w, h)
+    c = cfg(flip=True, flip_angle=180, wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=True, cc=True, gamma=True,
+            gamma_k=0.8, vig=True, undistort=True, cam=cam)
+    configure(pipe, c)
+    pipe.reset_white_balance_temporal_consistency()
+    pipe.set_ring_depth(depth)
+    frames = [synth.gen_frame(w, h, "bayer_rggb8", seed=700 + i, kind="scene", tint=(0.55 + 0.012 * i, 1.0, 0.62 - 0.008 * i)) for i in range(n)]
+    refs = [oracle_run(oracle, c, f, "bayer_rggb8", ccc=occ, taps=True) for f in frames]
+    # at most depth - 1 frames in flight while a collected view is still being read (depth 1: strictly one after the other)
+    in_flight = max(1, depth - 1)
+    tickets, got = [], {}
+    for i, f in enumerate(frames):
+        if len(tickets) == in_flight:
+            # collect the NEWEST first now and then: any outstanding ticket may be collected
+            j, t = tickets.pop(-1 if (i % 5 == 0 and in_flight > 1) else 0)
+            view = pipe.collect(t, copy=False)
+            if depth > 1:  # the view and the taps of the collected frame survive the next submit
+                tickets.append((i, pipe.submit(f, "bayer_rggb8")))
+            got[j] = view.copy()
+            assert_images_equal(pipe.get_dist_color_image(), refs[j][3].reshape(h, w, 3), "tap of collected frame %d" % j)
+            if depth > 1:
+                continue
+        tickets.append((i, pipe.submit(f, "bayer_rggb8")))
+    for j, t in tickets:
+        got[j] = pipe.collect(t)
+    # a full ring refuses one frame more and stays as it is
+    extra = [pipe.submit(frames[0], "bayer_rggb8") for _ in range(depth)]
+    with pytest.raises(RipError, match="in flight"):
+        pipe.submit(frames[0], "bayer_rggb8")
+    for t in extra:
+        pipe.collect(t)
+    with pytest.raises(ValueError):
+        pipe.collect(10 ** 9)
+    for i in range(n):
+        assert_images_equal(got[i], refs[i][0], "submit/collect frame %d (depth %d)" % (i, depth))
+    assert pipe.last_encoding == "bgr8"

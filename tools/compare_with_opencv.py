@@ -132,6 +132,35 @@ def stages(cv2, O, synth):
         yield "resize_360x270", "convolutional_color_constancy.cpp:97 from %dx%d" % (w, h), cv2.resize(img, (360, 270)), O.resize_linear(img, 270, 360)
 
 
+def contraction_fingerprint(cv2, O, synth):
+    """Which floating-point contraction model does THIS OpenCV build implement?  The float stages (colour matrix: cv::gemm's
+    3-term dot product; colour enhancer: HSV2RGB's v * (1 - s * f)) are run over all 2^24 colours through OpenCV and through
+    the oracle in its three models (oracle/rip_oracle.c: 0 none = what the HIP kernels implement, 1 GCC / Clang fma order, 2
+    the other association); the model with zero mismatches is the build's.  tests/test_fp_contraction.py bounds the models
+    against each other (<= 1 LSB, a few values per million), so whichever matches, the kernels are within that bound."""
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    M = np.asarray(synth.COLOR_MATRIX, np.float64).reshape(3, 3)
+    flat = img.reshape(-1, 3).astype(np.float32)
+    mixed = cv2.gemm(flat, np.ascontiguousarray(M.astype(np.float32).T), 1.0, None, 0.0)
+    ref_cc = np.clip(np.rint(mixed), 0, 255).astype(np.uint8).reshape(img.shape)
+    hsv = cv2.cvtColor(img, cv2.COLOR_BGR2HSV)
+    ref_ce = cv2.cvtColor(cv2.multiply(hsv, np.array((1.0, 1.2, 1.0, 0.0), np.float64)), cv2.COLOR_HSV2BGR)
+    out = {}
+    for stage, ref, run in (("color_matrix", ref_cc, lambda: O.color_matrix(img, M.ravel(), (0.0, 0.0, 0.0))),
+                            ("color_enhancer", ref_ce, lambda: O.color_enhance(img, 1.0, 1.2, 1.0))):
+        mism = []
+        for mode in (0, 1, 2):
+            with O.fp_contraction(mode):
+                got = run()
+            mism.append(int((got != ref).sum()))
+        best = int(np.argmin(mism))
+        out[stage] = (best, mism)
+        print("contraction fingerprint %-15s mismatching channel values per oracle model 0 / 1 / 2: %s -> this OpenCV build %s"
+              % (stage, mism, ("matches model %d exactly" % best) if mism[best] == 0 else "matches NO model exactly (closest: %d)" % best))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true", help="freeze OpenCV's outputs into tests/golden/opencv_vectors.npz")
@@ -171,6 +200,10 @@ def main():
                 frozen["%03d_%s_arg%d" % (i, name, k)] = np.asarray(a)
             frozen["%03d_%s_bar" % (i, name)] = np.array(bar)
     print("\nworst per stage:", worst)
+    import oracle as plain_oracle
+    for stage, (best, mism) in contraction_fingerprint(cv2, plain_oracle, synth).items():
+        frozen["fp_contraction_%s_model" % stage] = np.array(best)
+        frozen["fp_contraction_%s_mismatches" % stage] = np.array(mism)
     if args.write:
         np.savez_compressed(OUT, opencv_version=np.array(cv2.__version__), **frozen)
         print("wrote", OUT)

@@ -24,6 +24,38 @@ for _ in range(reps):
     ts.append(time.perf_counter() - t0)
 ts = np.array(ts) * 1e3
 print("process() host->host 1 frame: median %.3f ms  min %.3f  p90 %.3f   (%.0f frames/s)" % (np.median(ts), ts.min(), np.percentile(ts, 90), 1e3 / np.median(ts)))
+# pipelined host -> host: rip_submit / rip_collect with `depth` frames in flight (upload f+1 | kernels f | download f-1)
+def pipelined(p, src, depth, n=200, copy=False):
+    p.set_ring_depth(depth)
+    tickets = []
+    for _ in range(depth):  # warm the slots
+        tickets.append(p.submit(src, "bayer_rggb8"))
+    while tickets:
+        p.collect(tickets.pop(0), copy=copy)
+    t0 = time.perf_counter()
+    for i in range(n):
+        if len(tickets) == depth:
+            p.collect(tickets.pop(0), copy=copy)
+        tickets.append(p.submit(src, "bayer_rggb8"))
+    while tickets:
+        p.collect(tickets.pop(0), copy=copy)
+    return (time.perf_counter() - t0) / n * 1e3
+
+import ctypes
+lib = pipe._lib
+lib.rip_host_alloc.restype = ctypes.c_void_p
+lib.rip_host_alloc.argtypes = [ctypes.c_size_t]
+ptr = lib.rip_host_alloc(frame.nbytes)
+pinned = np.frombuffer((ctypes.c_uint8 * frame.nbytes).from_address(ptr), np.uint8).reshape(frame.shape)
+pinned[...] = frame
+for depth in (1, 2, 3, 4):
+    a = pipelined(pipe, frame, depth)
+    b = pipelined(pipe, pinned, depth)
+    print("submit/collect depth %d, pinned result view: pageable input %.3f ms/frame (%.0f frames/s) | pinned input %.3f ms/frame (%.0f frames/s)"
+          % (depth, a, 1e3 / a, b, 1e3 / b))
+c = pipelined(pipe, pinned, 3, copy=True)
+print("submit/collect depth 3, pinned input, result copied out of the pinned buffer: %.3f ms/frame (%.0f frames/s)" % (c, 1e3 / c))
+pipe.set_ring_depth(3)
 dev = torch.from_numpy(frame[None]).cuda()
 o = torch.empty((1, H, W, 3), dtype=torch.uint8, device="cuda")
 pipe.set_stream(torch.cuda.current_stream())
