@@ -139,27 +139,47 @@ constexpr int fast_threads() {
 }
 template <int BITS>
 constexpr int fast_waves_per_simd() {
-  return (BITS & ST_VIG) ? kVigWavesPerSimd : 1;
+  // vignetting + enhancer: 56 KB of tables, two workgroups per CU
+  return (BITS & ST_VIG) ? ((BITS & ST_HSV) ? 4 : kVigWavesPerSimd) : 1;
 }
 
-// The per-pixel stages after the demosaic for the four pixels of one row.
+// The per-pixel stages after the demosaic for the four pixels of one row; returns the 12 interleaved output bytes.
 template <int BITS, int WB>
-__device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const CcRegs& cc,
-                                           const HsvRegs& hr, const float (&mask)[4], int (&q)[4][3]) {
+__device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const CcRegs& cc,
+                                            const HsvRegs& hr, const float (&mask)[4], int (&q)[4][3]) {
 #pragma unroll
   for (int k = 0; k < 4; k++) apply_wb(WB, w, q[k][0], q[k][1], q[k][2]);
-  if constexpr ((BITS & ST_CC) != 0) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
-  }
   if constexpr ((BITS & ST_VIG) != 0) {
+    // byte offsets into VigTabs::lin (gamma folded into that table by the host)
+    unsigned lin_off[4][3], out_idx[4][3];
 #pragma unroll
-    for (int k0 = 0; k0 < 4; k0 += kVigGroup) vignette_n<kVigGroup>(tb.vig.v, mask + k0, q + k0);  // gamma folded into VigTabs::lin by the host
-  } else if constexpr ((BITS & ST_GAMMA) != 0) {
+    for (int k = 0; k < 4; k++) {
+      if constexpr ((BITS & ST_CC) != 0) {
+        float o[3];
+        apply_cc_f(p, cc, q[k][0], q[k][1], q[k][2], o);
+        // saturate_cast<uchar> into byte 1 of the dword: (v << 8) >> 6 = 4 v, a full-rate right shift
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+        for (int c = 0; c < 3; c++) lin_off[k][c] = __builtin_amdgcn_cvt_pk_u8_f32(o[c], 1, 0u) >> 6;
+      } else {
 #pragma unroll
-      for (int c = 0; c < 3; c++) q[k][c] = tb.gam.v.lut[q[k][c]];
+        for (int c = 0; c < 3; c++) lin_off[k][c] = (unsigned)q[k][c] << 2;
+      }
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < 4; k0 += kVigGroup) vignette_n<kVigGroup>(tb.vig.v, mask + k0, lin_off + k0, out_idx + k0);
+    if constexpr ((BITS & ST_HSV) == 0) return invg_pack4(out_idx);
+    invg_values4(out_idx, q);
+  } else {
+    if constexpr ((BITS & ST_CC) != 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
+    }
+    if constexpr ((BITS & ST_GAMMA) != 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) q[k][c] = tb.gam.v.lut[q[k][c]];
+    }
   }
   if constexpr ((BITS & ST_HSV) != 0) {
     if (hr.unit == 5u) {  // hue and value gains are 1 (the usual configuration scales the saturation only)
@@ -173,6 +193,7 @@ __device__ __forceinline__ void pointwise4(const ChainParams& p, const FrameWb& 
       asm volatile("s_nop 0 ; rip_generic_hsv_end");
     }
   }
+  return pack4(q);
 }
 
 template <int BITS, int WB, int NT>
@@ -278,8 +299,7 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
           q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
           q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
         }
-        pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, cc, hr, mask[ly], q);
-        store12(dst, dst_off[ly], pack4(q), dst_nt);
+        store12(dst, dst_off[ly], pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, cc, hr, mask[ly], q), dst_nt);
       }
     }
   }

@@ -44,6 +44,18 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// the same with the multiplier in a scalar register (a compile-time constant the loop keeps there)
+__device__ __forceinline__ int mad24_ks(int a, int k, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+  return d;
+}
+// ... and with the addend there
+__device__ __forceinline__ int mad24_cs(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
 __device__ __forceinline__ unsigned umulhi24(unsigned a, unsigned b) {
   return (unsigned)(((unsigned long long)(a & 0xffffffu) * (unsigned long long)(b & 0xffffffu)) >> 32);
 }
@@ -251,9 +263,8 @@ struct HsvRegs {
   }
 };
 // color_calibration.cpp:93-103: ((m0*B + m1*G) + m2*R) + bias in float32, no FMA
-__device__ __forceinline__ void apply_cc(const ChainParams& p, const CcRegs& cc, int& b, int& g, int& r) {
+__device__ __forceinline__ void apply_cc_f(const ChainParams& p, const CcRegs& cc, int b, int g, int r, float (&o)[3]) {
   float fb = (float)b, fg = (float)g, fr = (float)r;
-  float o[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) o[c] = fb * cc.m[c * 3] + fg * cc.m[c * 3 + 1] + fr * cc.m[c * 3 + 2];
   if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
@@ -261,6 +272,10 @@ __device__ __forceinline__ void apply_cc(const ChainParams& p, const CcRegs& cc,
 #pragma unroll
     for (int c = 0; c < 3; c++) o[c] = o[c] + p.cc_bias[c];
   }
+}
+__device__ __forceinline__ void apply_cc(const ChainParams& p, const CcRegs& cc, int& b, int& g, int& r) {
+  float o[3];
+  apply_cc_f(p, cc, b, g, r, o);
   b = sat_round_u8(o[0]);
   g = sat_round_u8(o[1]);
   r = sat_round_u8(o[2]);
@@ -394,21 +409,42 @@ constexpr int kLabInv[9] = {217, -836, 4715, -3773, 7684, 185, 12615, -6296, -22
 constexpr int kVigCbrtN = 2048;  // LabCbrtTab_b indices reachable from 8-bit input: 0 .. 2040
 constexpr int kZoff = 27500;     // z in [-999, 59828] -> z - kZoff fits int16
 constexpr int kVigGroup = 4;     // pixels of a row taken through the round trip together (ILP against live registers)
+// The descaled sums of Lab2RGBinteger stay inside [-7253, 16753] for every (L', a, b) (tests/test_oracle_known_answers.py::
+// test_ranges_the_fast_lab_kernel_relies_on), so sRGBInvGammaTab_b is held in LDS extended by its two saturated ends and
+// read without a clamp (three v_med3_i32 per pixel less); the offset is a multiple of 4 so that the middle of the table is
+// a dword copy, and it rides in the accumulators of the inverse matrix.
+constexpr int kInvgOff = 7256;
+constexpr int kInvgExtN = kInvgOff + 16753 + 3;  // 24012 bytes, a multiple of 4
+// adiv / bdiv of Lab2RGBinteger folded into ONE multiply-add each on top of a per-L' table word (VigTabs::yf[].x):
+//   fx = ify + ((5 a 53687 + 128) >> 13) - 4194            = (ify 2^13 + a kA + 128 - 4194 2^13) >> 13
+//   fz = ify - (((b 41943 + 16) >> 9) - 10484)             = (ify 2^13 + 10484 2^13 + 8191 - 256 - b kB16) >> 13
+// (kB16 = 16 * 41943; -floor(u / n) = floor((n - 1 - u) / n)).  The 24-bit multiplies read the low mantissa bits of the
+// floats that hold a and b, i.e. 0x400000 + a + kBiasA and 0x400000 + b + kBiasB; the biases are chosen (tools/
+// lab_fold_search.py) so that both formulas share the table word ify 2^13 + kFoldC, each within the slack its floor leaves
+// (x: [-31, +25], z: [-95, +128]; taken: -2 and +18).  tests/test_oracle_known_answers.py checks every (L', a, b).
+constexpr int kBiasA = -38465, kBiasB = -39212;
+constexpr unsigned kFoldA = 5u * 53687u, kFoldB16 = 16u * 41943u;
+constexpr unsigned kFoldC = 128u - 4194u * 8192u - 2u - kFoldA * (0x400000u + (unsigned)kBiasA);
 struct VigTabs {
   float lin[256];
   float cbx[kVigCbrtN];
   float2 cby[kVigCbrtN];
   int4 yf[256];
-  uint8_t invg[4096];
+  uint8_t invg[kInvgExtN];
   template <int NT>
   __device__ __forceinline__ void load(const DevTables* t) {
+    // the LDS address of a __shared__ object is the low half of its flat address
+    const unsigned invg_base = (unsigned)reinterpret_cast<uintptr_t>(&invg[0]);
     for (int i = threadIdx.x; i < 256; i += NT) {
       lin[i] = (float)t->lin_tab[i];
       const uint32_t e = t->yf_tab[i];
       const int y = (int)(e & 0xffffu);
       int4 o;
-      o.x = (int)(e >> 16);
-#define RIP_YACC(c) (kLabInv[(c) * 3 + 1] * y + (1 << 13) + kZoff * kLabInv[(c) * 3 + 2])
+      o.x = (int)(((e >> 16) << 13) + kFoldC);
+      // the accumulators of the inverse matrix carry the rounding constant, the z bias and the absolute LDS address of
+      // invg[kInvgOff], so that (sum >> 14) addresses the table entry directly
+      // (sums modulo 2^32, read back as unsigned)
+#define RIP_YACC(c) (int)((unsigned)(kLabInv[(c) * 3 + 1] * y + (1 << 13) + kZoff * kLabInv[(c) * 3 + 2]) + ((invg_base + kInvgOff) << 14))
       o.y = RIP_YACC(0);
       o.z = RIP_YACC(1);
       o.w = RIP_YACC(2);
@@ -425,53 +461,62 @@ struct VigTabs {
     }
     uint32_t* d = reinterpret_cast<uint32_t*>(invg);
     const uint32_t* s = reinterpret_cast<const uint32_t*>(t->inv_gamma);
-    for (int i = threadIdx.x; i < 1024; i += NT) d[i] = s[i];
+    const uint32_t below = 0x01010101u * t->inv_gamma[0], above = 0x01010101u * t->inv_gamma[4095];
+    for (int i = threadIdx.x; i < kInvgExtN / 4; i += NT) {
+      const int j = i - kInvgOff / 4;
+      d[i] = j < 0 ? below : j >= 1024 ? above : s[j];
+    }
   }
 };
-// Four pixels of one row through BGR -> Lab -> L * mask -> BGR (vignetting_correction.cpp:68-93).
+// Four pixels of one row through BGR -> Lab -> L * mask -> the three lookups that end Lab -> BGR
+// (vignetting_correction.cpp:68-93).  lin_off: byte offsets into VigTabs::lin (4 * value); out: absolute LDS byte addresses of the three VigTabs::invg entries.
+// Every table address leaves the arithmetic already scaled: shifts to the left are quarter-rate-class instructions on
+// gfx950 (4 cycles per wave64), right shifts, AND and the fp32 add are full rate (2).
 template <int N>
-__device__ __forceinline__ void vignette_n(const VigTabs& tb, const float* mask, int (*q)[3]) {
-  constexpr float kMagic = 12582912.0f;         // 1.5 * 2^23: ulp 1 in [2^23, 2^24)
-  constexpr unsigned kMagicBits = 0x4B400000u;  // its bit pattern
-  unsigned ix[N], iy[N], iz[N];
+__device__ __forceinline__ void vignette_n(const VigTabs& tb, const float* mask, const unsigned (*lin_off)[3], unsigned (*out)[3]) {
+  constexpr float kMagic = 12582912.0f;  // 1.5 * 2^23: ulp 1 in [2^23, 2^24); its bit pattern 0x4B400000 has 22 low zero bits
+  const char* lin_b = reinterpret_cast<const char*>(tb.lin);
+  const char* cbx_b = reinterpret_cast<const char*>(tb.cbx);
+  const char* cby_b = reinterpret_cast<const char*>(tb.cby);
+  const char* yf_b = reinterpret_cast<const char*>(tb.yf);
+  unsigned ax[N], ay[N], az[N];
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    const float v0 = tb.lin[q[k][0]], v1 = tb.lin[q[k][1]], v2 = tb.lin[q[k][2]];
-    // acc_r = (C_r . v + 0.5) / 4096, exact; RN(acc_r + magic) = (C_r . v + 2048) >> 12 (never a tie)
-    float acc[3] = {1.0f / 8192.0f, 1.0f / 8192.0f, 1.0f / 8192.0f};
+    const float v0 = *reinterpret_cast<const float*>(lin_b + lin_off[k][0]), v1 = *reinterpret_cast<const float*>(lin_b + lin_off[k][1]),
+                v2 = *reinterpret_cast<const float*>(lin_b + lin_off[k][2]);
+    // index i_r = (C_r . v + 2048) >> 12 = floor(s_r + 1/2), s_r = C_r . v / 4096 <= 2040.  The X and Z rows accumulate
+    // t = 4 s + 2 + (-1/2 + 2^-11) -- exact: multiples of 2^-11 below 2^13 -- and RN(t + magic) = floor(4 s + 2) (never a
+    // tie), whose bits above the low two are 4 i: the byte offset into the float table.  The Y row the same with 8 (float2).
+    float acc[3] = {1.5f + 1.0f / 2048.0f, 3.5f + 1.0f / 1024.0f, 1.5f + 1.0f / 2048.0f};
+    constexpr float sc[3] = {1.0f / 1024.0f, 1.0f / 512.0f, 1.0f / 1024.0f};
 #pragma unroll
     for (int r = 0; r < 3; r++)
-      acc[r] = __builtin_fmaf(v2, (float)kLabFwd[r * 3 + 2] * (1.0f / 4096.0f),
-                              __builtin_fmaf(v1, (float)kLabFwd[r * 3 + 1] * (1.0f / 4096.0f),
-                                             __builtin_fmaf(v0, (float)kLabFwd[r * 3] * (1.0f / 4096.0f), acc[r])));
-    ix[k] = __float_as_uint(acc[0] + kMagic) - kMagicBits;
-    iy[k] = __float_as_uint(acc[1] + kMagic) - kMagicBits;
-    iz[k] = __float_as_uint(acc[2] + kMagic) - kMagicBits;
+      acc[r] = __builtin_fmaf(v2, (float)kLabFwd[r * 3 + 2] * sc[r],
+                              __builtin_fmaf(v1, (float)kLabFwd[r * 3 + 1] * sc[r], __builtin_fmaf(v0, (float)kLabFwd[r * 3] * sc[r], acc[r])));
+    ax[k] = __float_as_uint(acc[0] + kMagic) & 0x1FFCu;
+    ay[k] = __float_as_uint(acc[1] + kMagic) & 0x3FF8u;
+    az[k] = __float_as_uint(acc[2] + kMagic) & 0x1FFCu;
   }
   int fx[N], fz[N], x[N], z[N];
   int4 e[N];
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    const float X = tb.cbx[ix[k]], Zt = tb.cbx[iz[k]];
-    const float2 LY = tb.cby[iy[k]];
-    const int L = sat_round_u8(LY.x * mask[k]);  // convertTo(32F), multiply, convertTo(8U)
-    // a, b never leave [0, 255] (exhaustive test), so saturate_cast is dead; abits = kMagicBits + a
-    const unsigned abits = __float_as_uint(__builtin_fmaf(X - LY.y, 5.0f / 8192.0f, kMagic + 128.0f));
+    const float X = *reinterpret_cast<const float*>(cbx_b + ax[k]), Zt = *reinterpret_cast<const float*>(cbx_b + az[k]);
+    const float2 LY = *reinterpret_cast<const float2*>(cby_b + ay[k]);
+    // L' = saturate_cast<uchar>(L * mask) (convertTo(32F), multiply, convertTo(8U)), placed in byte 1 of the dword:
+    // (L' << 8) >> 4 is the byte offset of its int4
+    const unsigned L16 = __builtin_amdgcn_cvt_pk_u8_f32(LY.x * mask[k], 1, 0u) >> 4;
+    // a, b never leave [0, 255] (exhaustive test), so saturate_cast is dead; the floats hold 0x400000 + a + kBiasA (b: kBiasB)
+    // in their low 24 bits
+    const unsigned abits = __float_as_uint(__builtin_fmaf(X - LY.y, 5.0f / 8192.0f, kMagic + (float)(128 + kBiasA)));
     // 25 fY - (25 fZ + 1/8) + 1/4 = 25 (fY - fZ) + 1/8, exact (multiples of 1/8 below 2^20)
-    const unsigned bbits = __float_as_uint(__builtin_fmaf((LY.y - Zt) + 0.25f, 1.0f / 4096.0f, kMagic + 128.0f));
-    e[k] = tb.yf[L];
-    // adiv = ((5 * a * 53687 + 128) >> 13) - 128 * BASE / 500, bdiv = ((b * 41943 + 16) >> 9) - 128 * BASE / 200 + 1:
-    // the 24-bit multiply reads 0x400000 + a; the constant takes 0x400000 * K back and carries the subtrahend
-    // times 2^shift, so one multiply-add and one arithmetic shift give the signed result.
-    constexpr unsigned kA = 5u * 53687u, kB = 41943u;
-    constexpr unsigned cA = (1u << 7) - 0x400000u * kA - ((128u * 16384u / 500u) << 13);
-    constexpr unsigned cB = (1u << 4) - 0x400000u * kB - ((128u * 16384u / 200u - 1u) << 9);
-    const int adiv = (int)(__umul24(abits, kA) + cA) >> 13;
-    const int bdiv = (int)(__umul24(bbits, kB) + cB) >> 9;
-    fx[k] = e[k].x + adiv;
-    fz[k] = e[k].x - bdiv;
+    const unsigned bbits = __float_as_uint(__builtin_fmaf((LY.y - Zt) + 0.25f, 1.0f / 4096.0f, kMagic + (float)(128 + kBiasB)));
+    e[k] = *reinterpret_cast<const int4*>(yf_b + L16);
+    fx[k] = (int)(__umul24(abits, kFoldA) + (unsigned)e[k].x) >> 13;
+    fz[k] = mad24_ks((int)bbits, -(int)kFoldB16, e[k].x) >> 13;
     x[k] = ab_to_xz_cube(fx[k]);
-    z[k] = ab_to_xz_cube(fz[k]);
+    // z - kZoff: the subtrahend rides in the second multiply
+    z[k] = mad24_cs(mul24(fz[k], fz[k]) >> 14, fz[k], -(kZoff << 14)) >> 14;
   }
   // abToXZ_b's linear segment (i <= 3390: L* below ~8) is rare: one wave-uniform test for the group
   int lo = min(fx[0], fz[0]);
@@ -481,24 +526,63 @@ __device__ __forceinline__ void vignette_n(const VigTabs& tb, const float* mask,
 #pragma unroll
     for (int k = 0; k < N; k++) {
       if (fx[k] <= 3390) x[k] = ab_to_xz_linear(fx[k]);
-      if (fz[k] <= 3390) z[k] = ab_to_xz_linear(fz[k]);
+      if (fz[k] <= 3390) z[k] = ab_to_xz_linear(fz[k]) - kZoff;
     }
   }
 #pragma unroll
   for (int k = 0; k < N; k++) {
     // {x, z - kZoff} as int16 pair; x in [-361, 28027]
-    const i16x2 xz = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm((uint32_t)(z[k] - kZoff), (uint32_t)x[k], 0x05040100u));
+    const i16x2 xz = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm((uint32_t)z[k], (uint32_t)x[k], 0x05040100u));
     constexpr i16x2 cb = {(short)kLabInv[0], (short)kLabInv[2]}, cg = {(short)kLabInv[3], (short)kLabInv[5]},
                     cr = {(short)kLabInv[6], (short)kLabInv[8]};
-    const int bo = __builtin_amdgcn_sdot2(xz, cb, e[k].y, false) >> 14;
-    const int go = __builtin_amdgcn_sdot2(xz, cg, e[k].z, false) >> 14;
-    const int ro = __builtin_amdgcn_sdot2(xz, cr, e[k].w, false) >> 14;
     // (the 4 KB sRGBInvGammaTab_b served by buffer_load_ubyte gathers from L1 instead of LDS: 2.43 -> 3.07 ms per 256
     // frames, round 3 -- a wave's 64 scattered bytes cost the texture path more than the LDS bank conflicts they avoid)
-    q[k][0] = tb.invg[clampi(bo, 0, 4095)];
-    q[k][1] = tb.invg[clampi(go, 0, 4095)];
-    q[k][2] = tb.invg[clampi(ro, 0, 4095)];
+    out[k][0] = (unsigned)__builtin_amdgcn_sdot2(xz, cb, e[k].y, false) >> 14;
+    out[k][1] = (unsigned)__builtin_amdgcn_sdot2(xz, cg, e[k].z, false) >> 14;
+    out[k][2] = (unsigned)__builtin_amdgcn_sdot2(xz, cr, e[k].w, false) >> 14;
   }
+}
+
+// The sRGBInvGammaTab_b lookups that end the round trip.  `addr` are absolute LDS byte addresses (vignette_n).  On gfx950
+// (SRAM-ECC on) the d16 LDS loads do not preserve the other half of their destination, they zero it
+// (tools/probes/d16_probe.hip): ds_read_u8_d16_hi returns byte << 16.  Bytes 0 and 1 of an output dword are read with
+// ds_read_u8, bytes 2 and 3 with ds_read_u8_d16_hi, and the dword is ((C | D') << 8) | (A | B'): two full-rate ORs and one
+// v_lshl_or_b32 instead of two shifts, a shift-or and a three-way or.  hipcc does not emit the d16 forms (it merges byte
+// reads with v_perm_b32), hence the inline assembly; LDS data returns in order, so the one s_waitcnt that closes the group
+// covers every read, and it ties the registers so that no consumer is scheduled above it.
+__device__ __forceinline__ void lds_u8(uint32_t& d, unsigned addr) { asm volatile("ds_read_u8 %0, %1" : "=v"(d) : "v"(addr)); }
+__device__ __forceinline__ void lds_u8_hi(uint32_t& d, unsigned addr) { asm volatile("ds_read_u8_d16_hi %0, %1" : "=v"(d) : "v"(addr)); }
+struct Pack3 {
+  uint32_t a, b, c;
+};
+__device__ __forceinline__ Pack3 invg_pack4(const unsigned (&addr)[4][3]) {
+  const unsigned* f = &addr[0][0];  // output byte j comes from f[j]
+  uint32_t v[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) {
+    if ((j & 3) < 2)
+      lds_u8(v[j], f[j]);
+    else
+      lds_u8_hi(v[j], f[j]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                 "+v"(v[10]), "+v"(v[11]));
+  Pack3 o;
+  o.a = ((v[1] | v[3]) << 8) | (v[0] | v[2]);
+  o.b = ((v[5] | v[7]) << 8) | (v[4] | v[6]);
+  o.c = ((v[9] | v[11]) << 8) | (v[8] | v[10]);
+  return o;
+}
+// the same lookups as separate values (a stage follows: the colour enhancer)
+__device__ __forceinline__ void invg_values4(const unsigned (&addr)[4][3], int (&q)[4][3]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) asm volatile("ds_read_u8 %0, %1" : "=v"(q[k][c]) : "v"(addr[k][c]));
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[2][0]), "+v"(q[2][1]),
+                 "+v"(q[2][2]), "+v"(q[3][0]), "+v"(q[3][1]), "+v"(q[3][2]));
 }
 
 // max / min of two floats with the VOP3 output clamp to [0, 1]: one instruction (hipcc turns __saturatef into two compares
@@ -796,9 +880,6 @@ __device__ __forceinline__ void interleave4(const Planar& v, uint32_t& d0, uint3
   d2 = __builtin_amdgcn_perm(v.r, bg23, 0x07030206u);                  // R2 B3 G3 R3
 }
 
-struct Pack3 {
-  uint32_t a, b, c;
-};
 // packs four BGR pixels (in the given order) into 12 bytes
 __device__ __forceinline__ Pack3 pack4(const int (&q)[4][3]) {
   Pack3 o;

@@ -623,9 +623,18 @@ def test_ranges_the_fast_lab_kernel_relies_on(oracle):
     assert -32768 <= x.min() and x.max() <= 32767
     assert -32768 <= z.min() - 27500 and z.max() - 27500 <= 32767, (z.min(), z.max())
     xb, yb, zb = np.broadcast_arrays(x, y, z)
+    lo, hi = 1 << 40, -(1 << 40)
     for c in range(3):
         s = inv[c * 3] * xb + inv[c * 3 + 1] * yb + inv[c * 3 + 2] * zb + (1 << 13)
         assert np.abs(s).max() < 2 ** 31
+        lo, hi = min(lo, int((s >> 14).min())), max(hi, int((s >> 14).max()))
+    # (4) the descaled sums index sRGBInvGammaTab_b after a clamp to [0, 4095]; the fast kernel reads a table extended by its
+    # saturated ends instead (VigTabs::invg, kInvgOff = 7256, kInvgExtN = 24012) and adds the table's LDS address
+    # (< 160 KB) to the accumulators, whose sum is taken modulo 2^32 and shifted as an unsigned number: the index range,
+    # and the address fits the 18 bits above the 14 fraction bits
+    assert (lo, hi) == (-7253, 16753)
+    assert 0 <= lo + 7256 and hi + 7256 < 24012
+    assert hi + 7256 + 160 * 1024 < 2 ** 18
     cb = np.unique(oracle.table("cbrt")[:2048].astype(np.int64))
     fX, fY = cb[:, None], cb[None, :]
     for k, sh, mul in ((500, 15, 5.0 / 8192.0), (200, 15, 1.0 / 4096.0)):
@@ -634,6 +643,53 @@ def test_ranges_the_fast_lab_kernel_relies_on(oracle):
         got = np.rint(d.astype(np.float64) * mul).astype(np.int64) + 128  # one rounding, as the FMA into 1.5 * 2^23 + 128 does
         assert np.array_equal(got, want), k
         assert not np.any(np.abs((d.astype(np.float64) * mul) % 1 - 0.5) < 1e-12)  # never a tie
+
+
+def test_lab_inverse_offsets_as_one_multiply_add_each(oracle):
+    """rip_device.hpp vignette_n: fx = ify + adiv(a) and fz = ify - bdiv(b) of Lab2RGBinteger as one 24-bit multiply-add
+    each on top of one shared table word per L' (kBiasA, kBiasB, kFoldC; tools/lab_fold_search.py) -- emulated with the
+    instructions' 24-bit operand and 32-bit wrap-around semantics for every (L', a, b), a and b over all of [0, 255]."""
+    M = 1 << 32
+    kA, kB16, bias_a, bias_b = 5 * 53687, 16 * 41943, -38465, -39212
+    fold_c = (128 - 4194 * 8192 - 2 - kA * (0x400000 + bias_a)) % M
+    assert fold_c == 0x40A41FD1
+    ify = oracle.table("lab_to_yf").astype(np.int64)[1::2][:, None]
+    word = (ify * 8192 + fold_c) % M
+    s32 = lambda v: np.where(v % M >= M // 2, v % M - M, v % M)
+    v = np.arange(256)[None, :]
+    # the floats hold magic + 128 + bias + (a - 128): their low 24 bits are what v_mad_u32_u24 / v_mad_i32_i24 read
+    magic = 12582912
+    for bias in (bias_a, bias_b):
+        f = np.float32(magic + 128 + bias) + (v - 128).astype(np.float32)
+        assert np.all(f >= 2 ** 23) and np.all(f < 2 ** 24)
+    va = (np.float32(magic + 128 + bias_a) + (v - 128).astype(np.float32)).view(np.uint32).astype(np.int64) & 0xFFFFFF
+    vb = (np.float32(magic + 128 + bias_b) + (v - 128).astype(np.float32)).view(np.uint32).astype(np.int64) & 0xFFFFFF
+    assert np.array_equal(va, 0x400000 + v + bias_a) and np.array_equal(vb, 0x400000 + v + bias_b) and vb.max() < 2 ** 23
+    fx = s32(va * kA + word) >> 13
+    fz = s32(word - vb * kB16) >> 13
+    assert np.array_equal(fx, ify + ((5 * v * 53687 + 128) >> 13) - 128 * 16384 // 500)
+    assert np.array_equal(fz, ify - (((v * 41943 + 16) >> 9) - 128 * 16384 // 200 + 1))
+
+
+def test_lab_forward_indices_as_scaled_byte_offsets(oracle):
+    """rip_device.hpp vignette_n: the cube-root table index (C . v + 2048) >> 12 leaves the fp32 arithmetic as a byte offset
+    (4 i for the float table, 8 i for the float2 one): t = k (C . v) / 4096 + k / 2 - 1/2 + 2^-11 accumulated exactly,
+    RN(t + 1.5 * 2^23) and an AND.  Emulated in float32 for every row of the forward matrix over a grid of table values
+    that contains the extremes and every residue of the sums."""
+    g = np.unique(oracle.table("srgb_gamma").astype(np.int64))
+    C = oracle.table("fwd_coeffs").astype(np.int64).reshape(3, 3)
+    rng = np.random.default_rng(5)
+    v = np.concatenate([np.array([[0, 0, 0], [2040, 2040, 2040], [2040, 0, 0], [0, 2040, 0], [0, 0, 2040]]), g[rng.integers(0, len(g), (200000, 3))]])
+    for k, init, mask in ((4, 1.5 + 2.0 ** -11, 0x1FFC), (8, 3.5 + 2.0 ** -10, 0x3FF8)):
+        for r in range(3):
+            acc = np.full(len(v), np.float32(init), np.float32)
+            for j in range(3):  # v_fma_f32: exact products and sums here, so a float64 evaluation rounded once is the same
+                t = acc.astype(np.float64) + v[:, j] * (np.float32(C[r, j]) * np.float32(k / 4096.0)).astype(np.float64)
+                acc = t.astype(np.float32)
+                assert np.array_equal(acc.astype(np.float64), t)  # every partial sum is exactly representable
+            bits = (acc + np.float32(12582912.0)).view(np.uint32)
+            want = (v @ C[r] + 2048) >> 12
+            assert np.array_equal((bits & mask).astype(np.int64), k * want)
 
 
 def test_four_tap_average_from_two_tap_averages():
