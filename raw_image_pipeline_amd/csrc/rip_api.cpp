@@ -191,6 +191,9 @@ struct rip_pipeline {
   bool plan_uploaded = false;
   bool use_tiled_remap = true;
   int last_batch_frames = 0;
+  // prefix of d_stats known to hold zeroed FrameStats records (the grey-world / pca statistics kernels clean up after themselves)
+  const void* stats_clean_ptr = nullptr;
+  size_t stats_clean_cap = 0, stats_clean_bytes = 0;  // (pointer, capacity) identify the allocation: DevBuf only ever grows
   // cross-kernel overlap inside one batch (run_batch): the remap of frame group g runs on this internal stream while the
   // statistics and the fused chain of group g + 1 run on the caller's stream
   hipStream_t aux_stream = nullptr;
@@ -639,6 +642,8 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   // exactly as without the split.  Measured on config2 (256 frames, one box, round 3): 4.87 ms per step unsplit; mode 1 with
   // 2 / 4 / 8 / 16 groups 4.98 / 5.00 / 5.09 / 5.70; mode 2 with 2 / 4 groups 4.94 / 5.05 -- the three kernels lean on the
   // same VALU issue slots and LDS, and the shorter launches pay their tails, so the default stays 1.
+  bool stats_cleared_here = false;
+  const size_t stats_clean_before = (p->stats_clean_ptr == p->d_stats.ptr && p->stats_clean_cap == p->d_stats.cap) ? p->stats_clean_bytes : 0;
   int groups = 1;
   if (pl.remap && !reuse_wb && p->tn.overlap_groups > 1) groups = std::min(p->tn.overlap_groups, n);
   hipStream_t front = p->stream, back = p->stream;
@@ -675,7 +680,17 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     } else if (sums) {
       rip::FrameStats* stats_g = p->d_stats.as<rip::FrameStats>() + f0;
       unsigned* hist_g = pl.wb_mode == rip::WB_SIMPLE ? p->d_hist.as<unsigned>() + (size_t)f0 * 768 : nullptr;
-      HIP_CHECK(hipMemsetAsync(stats_g, 0, sizeof(rip::FrameStats) * (size_t)ng, front));
+      // grey-world / pca: the statistics kernel itself finishes a frame (gains written by the workgroup that ends last) and
+      // hands its FrameStats back zeroed, so neither a memset nor a finalisation launch separates the batches -- two
+      // dependent launches less on the single-frame path.  The records are cleared here only when they are not known to be
+      // clean: fresh memory, or a batch that did not run to its end.
+      const bool fused_finalize = pl.wb_mode != rip::WB_SIMPLE;
+      const size_t stats_bytes = sizeof(rip::FrameStats) * (size_t)n;
+      if (!fused_finalize || stats_clean_before < stats_bytes) {
+        HIP_CHECK(hipMemsetAsync(stats_g, 0, sizeof(rip::FrameStats) * (size_t)ng, front));
+        stats_cleared_here = true;
+      }
+      p->stats_clean_bytes = 0;  // until this batch has been enqueued completely
       if (hist_g) HIP_CHECK(hipMemsetAsync(hist_g, 0, (size_t)ng * 768 * sizeof(unsigned), front));
       rip::StatsParams sp = {};
       sp.src = in_g;
@@ -691,13 +706,15 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
       sp.thresh255 = (unsigned)(uint16_t)std::lrintf((float)p->m.wb_bright_thr * 255);
       sp.stats = stats_g;
       sp.hist3 = hist_g;
+      sp.wb_out = fused_finalize ? wb_g : nullptr;
       {
         ProfScope ps(p, RIP_KERNEL_STATS, front);
         rip::launch_stats(sp, p->tn, front);
       }
       // SimpleWB::setP(clipping_percentile_) (white_balance.cpp:55); total = pixels per channel plane
-      rip::launch_wb_finalize(pl.wb_mode, sp.stats, nullptr, nullptr, p->d_tabs.as<rip::DevTables>(), wb_g, ng, front, sp.hist3,
-                              (float)p->m.wb_percentile, rows * cols);
+      if (!fused_finalize)
+        rip::launch_wb_finalize(pl.wb_mode, sp.stats, nullptr, nullptr, p->d_tabs.as<rip::DevTables>(), wb_g, ng, front, sp.hist3,
+                                (float)p->m.wb_percentile, rows * cols);
     } else if (pl.wb_mode == rip::WB_FLOAT) {
       rip::CccParams cp = {};  // the launcher zeroes the histogram when its kernel accumulates in HBM
       cp.src = in_g;
@@ -828,6 +845,12 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   p->last_batch_frames = n;
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) throw DeviceError(std::string("kernel launch failed: ") + hipGetErrorString(le));
+  if (sums && !reuse_wb && pl.wb_mode != rip::WB_SIMPLE) {  // every statistics launch went out: its records come back zeroed
+    p->stats_clean_ptr = p->d_stats.ptr;
+    p->stats_clean_cap = p->d_stats.cap;
+    p->stats_clean_bytes = std::max(stats_clean_before, sizeof(rip::FrameStats) * (size_t)n);
+  }
+  (void)stats_cleared_here;
 }
 
 // setDebug(true): raw_image_pipeline.hpp:143-172 writes the image after EVERY module -- enabled or not -- to

@@ -565,7 +565,10 @@ void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream) 
     // persistent grid: at most 256 CUs x 8 x 256 threads, a multiple of 8 workgroups (one share per XCD; the kernel
     // strides its chunk loop by gridDim.x / 8)
     // (the 512-thread vignetting variants run ~3 % faster with one chunk per workgroup than with a 768-workgroup persistent grid)
-    const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : (nt == kBlock ? 2048 : 4096)) * kBlock / nt / 8 * 8);
+    // a frame or two on the vignetting variants: three persistent workgroups per CU build the 54 KB of tables once each
+    // (67.4 us against 70.3 for the whole single-frame call with one workgroup per chunk: tools/probes/graph_probe.py)
+    const int dflt_blocks = nt == kBlock ? 2048 : (p.n_frames <= 2 ? 1536 : 4096);
+    const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : dflt_blocks) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
     dim3 grid(blocks, frame_groups(p, tn, cap, blocks));
     switch (p.stage_bits & 15) {

@@ -49,7 +49,7 @@ struct FrameWb {
 struct FrameStats {
   unsigned long long sum[5];  // grey-world: B,G,R ; pca: B, B^2, R, R^2, G
   unsigned int mx[3];         // pca: max B, R, G
-  unsigned int pad;
+  unsigned int done;          // workgroups that have added their part (fused finalisation, StatsParams::wb_out)
 };
 
 // Persistent ccc temporal state of one stream (convolutional_color_constancy.cpp:300-340).
@@ -112,6 +112,9 @@ struct StatsParams {
   unsigned thresh255;  // grey-world: cvRound(255 * thr)
   FrameStats* stats;   // [n_frames], zeroed
   unsigned* hist3;     // WB_SIMPLE: [n_frames][3][256] per-channel histograms, zeroed
+  // grey-world / pca: when set, the workgroup that finishes a frame last turns its sums into the frame's gains (wb_out[frame])
+  // and leaves the frame's FrameStats zeroed for the next batch -- no finalisation launch, no memset between batches
+  FrameWb* wb_out;
 };
 
 struct CccGeom {

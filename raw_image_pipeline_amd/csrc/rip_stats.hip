@@ -56,6 +56,45 @@ __device__ __forceinline__ void stat_hist_init(const StatsParams& p, unsigned* s
   __syncthreads();
 }
 
+// white_balance.cpp:59-64 (GrayworldWB) and :73-136 (pca): a frame's sums / maxima -> its gains
+__device__ __forceinline__ void solve2(float m00, float m01, float m10, float m11, float g0, float g1, float& o0, float& o1) {
+  // Eigen::Matrix2f::inverse() * vec (white_balance.cpp:104-115)
+  float det = m00 * m11 - m01 * m10;
+  float invdet = 1.0f / det;
+  float i00 = m11 * invdet, i01 = -m01 * invdet, i10 = -m10 * invdet, i11 = m00 * invdet;
+  o0 = i00 * g0 + i01 * g1;
+  o1 = i10 * g0 + i11 * g1;
+}
+__device__ __forceinline__ void wb_gains_from_sums(int mode, const FrameStats& fs, FrameWb& w) {
+  if (mode == WB_Q8) {
+    // GrayworldWBImpl::balanceWhite + applyChannelGains
+    double sb = (double)fs.sum[0], sg = (double)fs.sum[1], sr = (double)fs.sum[2];
+    double max_sum = fmax(sb, fmax(sr, sg));
+    float gb = sb < 0.1 ? 0.f : (float)(max_sum / sb);
+    float gg = sg < 0.1 ? 0.f : (float)(max_sum / sg);
+    float gr = sr < 0.1 ? 0.f : (float)(max_sum / sr);
+    float gmax = fmaxf(gb, fmaxf(gg, gr));
+    if (gmax > 0) {
+      gb /= gmax;
+      gg /= gmax;
+      gr /= gmax;
+    }
+    w.q8[0] = (int)__builtin_rintf(gb * 256.f);
+    w.q8[1] = (int)__builtin_rintf(gg * 256.f);
+    w.q8[2] = (int)__builtin_rintf(gr * 256.f);
+    w.fg[0] = gb;
+    w.fg[1] = gg;
+    w.fg[2] = gr;
+  } else if (mode == WB_PCA) {
+    double s_b = (double)fs.sum[0], s_b2 = (double)fs.sum[1], s_r = (double)fs.sum[2], s_r2 = (double)fs.sum[3],
+           s_g = (double)fs.sum[4];
+    float mb = (float)fs.mx[0], mr = (float)fs.mx[1], mg = (float)fs.mx[2];
+    float mb2 = mb * mb, mr2 = mr * mr;
+    solve2((float)s_b2, (float)s_b, mb2, mb, (float)s_g, mg, w.pca[0], w.pca[1]);
+    solve2((float)s_r2, (float)s_r, mr2, mr, (float)s_g, mg, w.pca[2], w.pca[3]);
+  }
+}
+
 __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, FrameStats* out, unsigned* s_hist, int frame) {
   if (p.mode == WB_SIMPLE) {
     __syncthreads();
@@ -76,14 +115,49 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
     if (lane == 0) sh[5 + k][wid] = v;
   }
   __syncthreads();
+  // With the fused finalisation the atomics return their old value: the thread then waits for it, i.e. until the update has
+  // been performed at the device's coherence point (agent-scope atomics execute beyond the per-XCD L2s), before the
+  // workgroup barrier below lets thread 0 draw the ticket.  A release fence instead (__threadfence) writes back the XCD's L2
+  // on gfx950 and made this kernel 13 x slower.
+  const bool fused = p.wb_out != nullptr;
   if (threadIdx.x < 5) {
     unsigned long long t = 0;
     for (int i = 0; i < kBlock / 64; i++) t += sh[threadIdx.x][i];
-    if (t) atomicAdd(&out->sum[threadIdx.x], t);
+    if (fused) {
+      const unsigned long long old = atomicAdd(&out->sum[threadIdx.x], t);
+      asm volatile("" ::"v"(old));
+    } else if (t) {
+      atomicAdd(&out->sum[threadIdx.x], t);
+    }
   } else if (threadIdx.x < 8 && p.mode == WB_PCA) {
     unsigned t = 0;
     for (int i = 0; i < kBlock / 64; i++) t = max(t, sh[threadIdx.x][i]);
-    atomicMax(&out->mx[threadIdx.x - 5], t);
+    if (fused) {
+      const unsigned old = atomicMax(&out->mx[threadIdx.x - 5], t);
+      asm volatile("" ::"v"(old));
+    } else {
+      atomicMax(&out->mx[threadIdx.x - 5], t);
+    }
+  }
+  if (!fused) return;
+  // Fused finalisation: every workgroup of the frame (gridDim.x of them) takes a ticket once its own updates have been
+  // performed; the one that draws the last ticket therefore sees all of them, writes the frame's gains and zeroes the
+  // record -- the next batch starts from a clean FrameStats without a memset.
+  __shared__ unsigned s_ticket;
+  __syncthreads();
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&out->done, 1u);
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;
+  if (threadIdx.x == 0) {
+    FrameStats fs;
+#pragma unroll
+    for (int k = 0; k < 5; k++) fs.sum[k] = atomicExch(&out->sum[k], 0ull);
+#pragma unroll
+    for (int k = 0; k < 3; k++) fs.mx[k] = atomicExch(&out->mx[k], 0u);
+    atomicExch(&out->done, 0u);
+    FrameWb w = {};
+    wb_gains_from_sums(p.mode, fs, w);
+    p.wb_out[frame] = w;
   }
 }
 
@@ -247,15 +321,6 @@ __global__ __launch_bounds__(kBlock) void stats_generic_kernel(StatsParams p) {
 // ------------------------------------------------------------------------------------------------
 // white-balance finalisation: statistics -> per-frame gains, on the device (no host round trip)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void solve2(float m00, float m01, float m10, float m11, float g0, float g1, float& o0, float& o1) {
-  // Eigen::Matrix2f::inverse() * vec (white_balance.cpp:104-115)
-  float det = m00 * m11 - m01 * m10;
-  float invdet = 1.0f / det;
-  float i00 = m11 * invdet, i01 = -m01 * invdet, i10 = -m10 * invdet, i11 = m00 * invdet;
-  o0 = i00 * g0 + i01 * g1;
-  o1 = i10 * g0 + i11 * g1;
-}
-
 __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* st,
                                    const DevTables* tabs, FrameWb* out, int n_frames, const unsigned* simple_hist,
                                    float simple_p, int simple_total) {
@@ -399,34 +464,7 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
     out[f] = w;
     return;
   }
-  const FrameStats& fs = stats[f];
-  if (mode == WB_Q8) {
-    // GrayworldWBImpl::balanceWhite + applyChannelGains
-    double sb = (double)fs.sum[0], sg = (double)fs.sum[1], sr = (double)fs.sum[2];
-    double max_sum = fmax(sb, fmax(sr, sg));
-    float gb = sb < 0.1 ? 0.f : (float)(max_sum / sb);
-    float gg = sg < 0.1 ? 0.f : (float)(max_sum / sg);
-    float gr = sr < 0.1 ? 0.f : (float)(max_sum / sr);
-    float gmax = fmaxf(gb, fmaxf(gg, gr));
-    if (gmax > 0) {
-      gb /= gmax;
-      gg /= gmax;
-      gr /= gmax;
-    }
-    w.q8[0] = (int)__builtin_rintf(gb * 256.f);
-    w.q8[1] = (int)__builtin_rintf(gg * 256.f);
-    w.q8[2] = (int)__builtin_rintf(gr * 256.f);
-    w.fg[0] = gb;
-    w.fg[1] = gg;
-    w.fg[2] = gr;
-  } else if (mode == WB_PCA) {
-    double s_b = (double)fs.sum[0], s_b2 = (double)fs.sum[1], s_r = (double)fs.sum[2], s_r2 = (double)fs.sum[3],
-           s_g = (double)fs.sum[4];
-    float mb = (float)fs.mx[0], mr = (float)fs.mx[1], mg = (float)fs.mx[2];
-    float mb2 = mb * mb, mr2 = mr * mr;
-    solve2((float)s_b2, (float)s_b, mb2, mb, (float)s_g, mg, w.pca[0], w.pca[1]);
-    solve2((float)s_r2, (float)s_r, mr2, mr, (float)s_g, mg, w.pca[2], w.pca[3]);
-  }
+  wb_gains_from_sums(mode, stats[f], w);
   out[f] = w;
 }
 
