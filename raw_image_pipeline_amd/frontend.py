@@ -138,7 +138,34 @@ class CameraStream:
         if self.transport != "raw":
             encoding = "bgr8"  # cv_bridge::toCvCopy(image_msg, "bgr8") for compressed transports
         processed = self.pipe.apply(img.copy(), encoding)
-        enc = self.pipe.last_encoding
+        return self._messages(processed, self.pipe.last_encoding, stamp, frame_id)
+
+    def on_image_pipelined(self, image, encoding, stamp=0.0, frame_id="camera"):
+        """The same callback with one frame kept in flight (rip_submit / rip_collect): uploads, kernels and downloads of
+        neighbouring frames overlap, and the call returns the messages of the PREVIOUS frame (an empty list for the first
+        one; flush() delivers the last).  Frames are processed in arrival order, so the white-balance filter sees the
+        same sequence as with on_image()."""
+        img = np.ascontiguousarray(image)
+        if img.size == 0:
+            return []
+        if self.transport != "raw":
+            encoding = "bgr8"
+        ticket = self.pipe.submit(img, encoding)
+        out = self.flush()
+        self._pending = (ticket, stamp, frame_id)
+        return out
+
+    def flush(self):
+        """Messages of the frame still in flight, if any."""
+        pending = getattr(self, "_pending", None)
+        if pending is None:
+            return []
+        self._pending = None
+        ticket, stamp, frame_id = pending
+        processed = self.pipe.collect(ticket)
+        return self._messages(processed, self.pipe.last_encoding, stamp, frame_id)
+
+    def _messages(self, processed, enc, stamp, frame_id):
         out = []
         pipe = self.pipe
         if pipe.is_undistortion_enabled():

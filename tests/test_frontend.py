@@ -81,6 +81,31 @@ def test_callback_topics_decimation_and_camera_info(rip_lib, oracle):
 
 
 @pytest.mark.gpu
+def test_pipelined_callback_publishes_what_the_synchronous_one_does(rip_lib):
+    """on_image_pipelined() keeps one frame in flight (rip_submit / rip_collect) and hands back the previous frame's
+    messages; over a stream -- grey-world white balance, taps, slow-topic decimation, camera info with the stamps of the
+    frames they belong to -- it must publish exactly the sequence on_image() publishes."""
+    w, h, n = 64, 48, 7
+    params = {"output_prefix": "/cam0", "output_encoding": "BGR", "skip_number_of_images_for_slow_topic": 2,
+              "flip/enabled": True, "flip/angle": 180, "gamma_correction/enabled": True, "gamma_correction/k": 0.9,
+              "white_balance/enabled": True, "white_balance/method": "gray_world",
+              "undistortion/enabled": True, "undistortion/calibration_file": os.path.join(CFG, "calib_64x48.yaml")}
+    frames = [synth.gen_frame(w, h, "bayer_rggb8", seed=80 + i, kind="scene", tint=(0.6 + 0.04 * i, 1.0, 0.5)) for i in range(n)]
+    sync = CameraStream(params, device=0)
+    want = [sync.on_image(f, "bayer_rggb8", stamp=2.0 + i, frame_id="c") for i, f in enumerate(frames)]
+    pipe = CameraStream(params, device=0)
+    got = [pipe.on_image_pipelined(f, "bayer_rggb8", stamp=2.0 + i, frame_id="c") for i, f in enumerate(frames)]
+    assert got[0] == []
+    got = got[1:] + [pipe.flush()]
+    assert pipe.flush() == []
+    for i in range(n):
+        assert [m["topic"] for m in got[i]] == [m["topic"] for m in want[i]], i
+        for a, b in zip(got[i], want[i]):
+            assert a["encoding"] == b["encoding"] and a["header"] == b["header"] and a["camera_info"] == b["camera_info"]
+            assert np.array_equal(a["image"], b["image"]), (i, a["topic"])
+
+
+@pytest.mark.gpu
 def test_compressed_transport_forces_bgr8(rip_lib):
     cam = CameraStream({"transport": "compressed", "output_encoding": "passthrough"}, device=0)
     img = synth.gen_scene_bgr(32, 24, seed=3)

@@ -268,6 +268,33 @@ def test_batch_with_many_frames_per_workgroup(gpu_pipe, oracle, monkeypatch, wb)
         assert_images_equal(out[i], ref, "frame %d of %d (%s)" % (i, n, wb))
 
 
+def test_statistics_records_are_handed_back_clean(gpu_pipe, oracle):
+    """The grey-world / pca statistics kernels finish their frames themselves: the workgroup that ends a frame last writes
+    its gains and zeroes the frame's record, and the library skips the memset and the finalisation launch for as long as
+    it knows the records are clean (rip_api.cpp run_batch).  One handle, batches of changing length, method, input kind and
+    geometry back to back (SimpleWB in between keeps its own finalisation kernel, colour input takes another statistics
+    kernel, a longer batch re-allocates the records): every frame of every batch must equal the oracle, i.e. no sum of an
+    earlier batch may survive and no ticket counter may be left half-way."""
+    import torch
+    steps = [("grey_world", 3, (128, 96), "bayer_rggb8"), ("grey_world", 3, (128, 96), "bayer_rggb8"), ("pca", 2, (128, 96), "bayer_rggb8"),
+             ("simple", 2, (128, 96), "bayer_rggb8"), ("grey_world", 5, (132, 36), "bayer_gbrg8"), ("pca", 1, (132, 36), "bayer_gbrg8"),
+             ("grey_world", 4, (64, 48), "bgr8"), ("pca", 4, (37, 29), "bayer_grbg8"), ("grey_world", 17, (128, 96), "bayer_rggb8"),
+             ("grey_world", 1, (128, 96), "bayer_rggb8"), ("pca", 9, (128, 96), "bayer_rggb8"), ("grey_world", 2, (640, 480), "bayer_rggb8")]
+    for k, (method, n, (w, h), enc) in enumerate(steps):
+        c = cfg(wb=True, wb_method=method, wb_bright=0.85, cc=True, gamma=True)
+        configure(gpu_pipe, c)
+        if enc == "bgr8":
+            frames = np.stack([synth.gen_scene_bgr(w, h, seed=70 * k + i, tint=(0.6 + 0.05 * i, 1.0, 0.5)) for i in range(n)])
+        else:
+            frames = np.stack([synth.gen_frame(w, h, enc, seed=70 * k + i, kind="scene", tint=(0.6 + 0.05 * i, 1.0, 0.5)) for i in range(n)])
+        out = gpu_pipe.apply_device(torch.from_numpy(frames).cuda(), enc)
+        torch.cuda.synchronize()
+        out = out.cpu().numpy()
+        for i in range(n):
+            ref, _ = oracle_run(oracle, c, frames[i], enc)
+            assert_images_equal(out[i], ref, "step %d (%s, %d frames of %dx%d %s), frame %d" % (k, method, n, w, h, enc, i))
+
+
 def test_very_long_batch_is_sliced(gpu_pipe, oracle):
     """More frames than a grid dimension holds: the batch goes through in slices of 16384; 40 000 tiny frames, a few
     of them checked against the oracle, all of them against the frame pattern they repeat."""
