@@ -772,7 +772,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     c.drows = pl.mid_rows;
     c.dcols = pl.mid_cols;
     c.channels = pl.channels;
-    c.dst_streaming = (!pl.remap && n >= 8) ? 1 : 0;
+    c.dst_streaming = (!pl.remap && n >= 8) ? 1 : 0;  // non-temporal stores for an image no kernel of this batch reads again (debayer-only, 256 frames: 1.08 against 1.16 ms)
     c.tap = d_tap_deb ? d_tap_deb + (size_t)f0 * tap_frame : nullptr;
     c.tap_frame_stride = tap_frame;
     c.flip_angle = pl.flip_angle;

@@ -533,15 +533,22 @@ bool chain_uses_rot_path(const ChainParams& p) {
 }
 
 // gridDim.y: how many groups of frames the batch is split into (every kernel here walks the frames of its group
-// innermost).  At most 16 frames per item visit (RIP_CHAIN_FRAMES): 2448 chunks on 2048 persistent workgroups would
-// leave most of the chip idle while a fifth of them does a second chunk; four times as many, shorter units let the
-// dispatcher even that out (config2: 0.80 -> 0.75 ms per 64 frames) and 16 frames still amortise the per-item setup
-// (FP64 vignetting mask, addresses).  The cheap stage sets (no Lab / HSV round trip) are HBM-bound and stream best one
-// frame at a time -- a frame is contiguous, the next frame of the batch is megabytes away (config5, debayer only:
-// 2.00 ms at 16 frames per visit, 1.65 ms at 1 = 5.1 TB/s).
+// innermost).  At most 16 frames per item visit (RIP_CHAIN_FRAMES) for the VALU-bound stage sets: 2448 chunks on 2048
+// persistent workgroups would leave most of the chip idle while a fifth of them does a second chunk; four times as many,
+// shorter units let the dispatcher even that out (config2: 0.80 -> 0.75 ms per 64 frames) and 16 frames still amortise the
+// per-item setup (mask, addresses).  The stage sets without Lab / HSV round trip run at the memory rate and want few
+// frames per visit -- a frame is contiguous, the next frame of the batch is megabytes away -- but not one: round 3,
+// 2448x2048, 256 frames, ms per launch at 1 / 2 / 4 / 8 / 16 frames per visit: demosaic only 1.17 / 1.09 / 1.09 / 1.26 / 1.35,
+// + grey-world gains . / 1.05 / 1.07 / 1.23 / 1.43, + gamma . / 1.15 / 1.09 / 1.23 / 1.39, + gains + colour matrix + gamma
+// 1.62 / 1.39 / 1.27 / 1.28 / 1.41; 3840x2160 demosaic only 1.76 / 1.70 / 1.80.  (Requesting the windows of two frames before
+// the first is demosaiced, or walking the (frame, chunk) pairs of a group in address order with long-lived workgroups,
+// measured equal or slower.)
 static int frame_groups(const ChainParams& p, const Tunables& tn, int cap, int blocks) {
   const bool valu_bound = (p.stage_bits & (ST_VIG | ST_HSV)) != 0;
-  const int frames_per_visit = tn.chain_frames > 0 ? tn.chain_frames : (valu_bound ? 16 : 1);
+  // memory-rate stage sets: two frames per visit (four once the colour matrix or the gamma table add per-pixel work) --
+  // the per-item setup is shared and a workgroup lives a little longer, while the frames it touches stay few
+  const int streaming = (p.stage_bits & (ST_CC | ST_GAMMA)) ? 4 : 2;
+  const int frames_per_visit = tn.chain_frames > 0 ? tn.chain_frames : (valu_bound ? 16 : streaming);
   const int groups = std::max(cap / std::max(blocks, 1), (p.n_frames + frames_per_visit - 1) / frames_per_visit);
   return std::max(1, std::min(p.n_frames, groups));
 }
