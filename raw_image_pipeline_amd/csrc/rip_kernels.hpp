@@ -45,11 +45,20 @@ struct FrameWb {
   int pad[2];
 };
 
-// Raw per-frame statistics (zeroed before each batch).
-struct FrameStats {
+// Raw per-frame statistics (zeroed before the first batch; the statistics kernels hand them back zeroed).  Every frame has
+// kStatShards records, one 128-byte line each: a workgroup adds its part to shard blockIdx.x % 8 (the XCD it runs on, by
+// dispatch order), so at most an eighth of a frame's workgroups queue up on one line's atomics -- a single frame's
+// 260 workgroups x 3 sums on ONE line were most of that kernel's 12 us.
+constexpr int kStatShards = 8;
+struct StatShard {
   unsigned long long sum[5];  // grey-world: B,G,R ; pca: B, B^2, R, R^2, G
   unsigned int mx[3];         // pca: max B, R, G
-  unsigned int done;          // workgroups that have added their part (fused finalisation, StatsParams::wb_out)
+  unsigned int done;          // shard 0 only: workgroups that have added their part (fused finalisation, StatsParams::wb_out)
+  unsigned long long pad[9];
+};
+static_assert(sizeof(StatShard) == 128, "one shard per 128-byte line");
+struct FrameStats {
+  StatShard shard[kStatShards];
 };
 
 // Persistent ccc temporal state of one stream (convolutional_color_constancy.cpp:300-340).

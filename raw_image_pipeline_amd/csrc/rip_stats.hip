@@ -65,7 +65,7 @@ __device__ __forceinline__ void solve2(float m00, float m01, float m10, float m1
   o0 = i00 * g0 + i01 * g1;
   o1 = i10 * g0 + i11 * g1;
 }
-__device__ __forceinline__ void wb_gains_from_sums(int mode, const FrameStats& fs, FrameWb& w) {
+__device__ __forceinline__ void wb_gains_from_sums(int mode, const StatShard& fs, FrameWb& w) {
   if (mode == WB_Q8) {
     // GrayworldWBImpl::balanceWhite + applyChannelGains
     double sb = (double)fs.sum[0], sg = (double)fs.sum[1], sr = (double)fs.sum[2];
@@ -120,41 +120,58 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
   // workgroup barrier below lets thread 0 draw the ticket.  A release fence instead (__threadfence) writes back the XCD's L2
   // on gfx950 and made this kernel 13 x slower.
   const bool fused = p.wb_out != nullptr;
+  StatShard* const mine = &out->shard[blockIdx.x % kStatShards];
   if (threadIdx.x < 5) {
     unsigned long long t = 0;
     for (int i = 0; i < kBlock / 64; i++) t += sh[threadIdx.x][i];
-    if (fused) {
-      const unsigned long long old = atomicAdd(&out->sum[threadIdx.x], t);
-      asm volatile("" ::"v"(old));
-    } else if (t) {
-      atomicAdd(&out->sum[threadIdx.x], t);
+    if (t) {
+      if (fused) {
+        const unsigned long long old = atomicAdd(&mine->sum[threadIdx.x], t);
+        asm volatile("" ::"v"(old));
+      } else {
+        atomicAdd(&mine->sum[threadIdx.x], t);
+      }
     }
   } else if (threadIdx.x < 8 && p.mode == WB_PCA) {
     unsigned t = 0;
     for (int i = 0; i < kBlock / 64; i++) t = max(t, sh[threadIdx.x][i]);
-    if (fused) {
-      const unsigned old = atomicMax(&out->mx[threadIdx.x - 5], t);
-      asm volatile("" ::"v"(old));
-    } else {
-      atomicMax(&out->mx[threadIdx.x - 5], t);
+    if (t) {
+      if (fused) {
+        const unsigned old = atomicMax(&mine->mx[threadIdx.x - 5], t);
+        asm volatile("" ::"v"(old));
+      } else {
+        atomicMax(&mine->mx[threadIdx.x - 5], t);
+      }
     }
   }
   if (!fused) return;
   // Fused finalisation: every workgroup of the frame (gridDim.x of them) takes a ticket once its own updates have been
-  // performed; the one that draws the last ticket therefore sees all of them, writes the frame's gains and zeroes the
-  // record -- the next batch starts from a clean FrameStats without a memset.
+  // performed; the one that draws the last ticket therefore sees all of them: it collects the shards (exchanging them
+  // for zeros: the next batch starts from clean records without a memset), adds them up and writes the frame's gains.
   __shared__ unsigned s_ticket;
+  __shared__ StatShard s_part[kStatShards];
   __syncthreads();
-  if (threadIdx.x == 0) s_ticket = atomicAdd(&out->done, 1u);
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&out->shard[0].done, 1u);
   __syncthreads();
   if (s_ticket != gridDim.x - 1) return;
+  if (threadIdx.x < kStatShards) {
+    StatShard* const src = &out->shard[threadIdx.x];
+    StatShard& dst = s_part[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < 5; k++) dst.sum[k] = atomicExch(&src->sum[k], 0ull);
+#pragma unroll
+    for (int k = 0; k < 3; k++) dst.mx[k] = atomicExch(&src->mx[k], 0u);
+    if (threadIdx.x == 0) atomicExch(&src->done, 0u);
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    FrameStats fs;
+    StatShard fs = s_part[0];
+    for (int i = 1; i < kStatShards; i++) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) fs.sum[k] = atomicExch(&out->sum[k], 0ull);
+      for (int k = 0; k < 5; k++) fs.sum[k] += s_part[i].sum[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) fs.mx[k] = atomicExch(&out->mx[k], 0u);
-    atomicExch(&out->done, 0u);
+      for (int k = 0; k < 3; k++) fs.mx[k] = max(fs.mx[k], s_part[i].mx[k]);
+    }
     FrameWb w = {};
     wb_gains_from_sums(p.mode, fs, w);
     p.wb_out[frame] = w;
@@ -464,7 +481,12 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
     out[f] = w;
     return;
   }
-  wb_gains_from_sums(mode, stats[f], w);
+  StatShard fs = stats[f].shard[0];
+  for (int i = 1; i < kStatShards; i++) {
+    for (int k = 0; k < 5; k++) fs.sum[k] += stats[f].shard[i].sum[k];
+    for (int k = 0; k < 3; k++) fs.mx[k] = max(fs.mx[k], stats[f].shard[i].mx[k]);
+  }
+  wb_gains_from_sums(mode, fs, w);
   out[f] = w;
 }
 
@@ -480,10 +502,10 @@ void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream) 
     // (pca: sum of squares) is 64 lanes * 8 px * 255^2 * pairs_per_task: 128 pairs keep it below 2^32
     const int groups = p.cols / 4, n_pairs = p.rows / 2;
     const int col_waves = (groups + 63) / 64;
-    // per frame: 512 wave tasks when the batch fills the chip anyway, at most 1024 for a single frame (more
-    // tasks only queue up on the three 64-bit atomics every workgroup ends with: 22 -> 12.6 us for one frame)
+    // per frame: 512 wave tasks when the batch fills the chip anyway, 2048 for a single frame (shorter row walks; with the
+    // sums sharded over eight lines the workgroups no longer queue up on one line's atomics: 65.1 -> 63.9 us per call)
     const int budget = grid_multiple_of_8(tn.stats_blocks) * 4;
-    const int target_tasks = std::max(8, std::min(budget / 8, budget / std::max(1, std::min(p.n_frames, 16))));
+    const int target_tasks = std::max(8, std::min(budget / (p.n_frames == 1 ? 4 : 8), budget / std::max(1, std::min(p.n_frames, 16))));
     int pairs_per_task = std::max(2, (int)(((long long)col_waves * n_pairs + target_tasks - 1) / target_tasks));
     pairs_per_task = std::min((pairs_per_task + 1) & ~1, 128);  // even: the kernel consumes two pairs per iteration
     const int n_tasks = col_waves * ((n_pairs + pairs_per_task - 1) / pairs_per_task);
