@@ -235,11 +235,7 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, int c
   // Block b runs on XCD b % 8 (observed dispatch order; speed only): every XCD takes a contiguous range of tasks, so that
   // neighbouring column strips -- whose 256-byte row segments straddle the same 128-byte lines when the row pitch is not
   // a multiple of 128 -- and vertically adjacent row ranges (two shared halo rows) meet in one L2.
-#ifdef RIP_X_STATS_NOXCD
-  const int logical_block = (int)blockIdx.x;
-#else
   const int logical_block = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-#endif
   const int task = __builtin_amdgcn_readfirstlane(logical_block * (kBlock / 64) + (int)(threadIdx.x >> 6));
   StatAcc a = {};
   if (task < n_tasks) {
