@@ -1667,7 +1667,7 @@ rip_status rip_set_tunable(rip_pipeline* p, const char* name, int value) {
     else if (n == "remap_ring") t.remap_ring = value;
     else if (n == "remap_stages") t.remap_stages = value > 0 ? value : dflt.remap_stages;
     else if (n == "remap_per_cu") t.remap_per_cu = value;
-    else if (n == "remap_frames") t.remap_frames = value > 0 ? value : dflt.remap_frames;
+    else if (n == "remap_frames") t.remap_frames = value;
     else if (n == "remap_tiled") p->use_tiled_remap = value != 0;
     else if (n == "ccc_lds_hist_min") t.ccc_lds_hist_min = value > 0 ? value : dflt.ccc_lds_hist_min;
     else if (n == "overlap_groups") t.overlap_groups = value;

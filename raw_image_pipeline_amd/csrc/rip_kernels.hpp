@@ -200,7 +200,7 @@ struct Tunables {
   int remap_ring = 1;         // RIP_REMAP_RING=0: register-pipelined tiled kernel instead of the LDS-DMA ring
   int remap_stages = 3;       // RIP_REMAP_STAGES: LDS ring size
   int remap_per_cu = 0;       // RIP_REMAP_PER_CU: resident workgroups per CU; 0 = 6 (ring) / 8 (tiled)
-  int remap_frames = 4;       // RIP_REMAP_FRAMES: frames per tile visit
+  int remap_frames = 0;       // RIP_REMAP_FRAMES: frames per tile visit (0: by the size of a source frame, 4 .. 12)
   int ccc_lds_hist_min = 48;  // RIP_CCC_LDS_HIST_MIN: smallest batch that takes the LDS histogram
   int overlap_groups = 0;     // RIP_OVERLAP_GROUPS: frame groups a batch is split into on the handle's internal streams (rip_api.cpp run_batch); 0 / 1 = off (the measured optimum)
   int overlap_mode = 1;       // RIP_OVERLAP_MODE: 1 = remap(g) beside stats(g+1) + chain(g+1); 2 = beside stats(g+1) only (the chain waits)

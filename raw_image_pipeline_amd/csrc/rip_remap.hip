@@ -484,11 +484,18 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
     blocks = std::max(8, blocks / 8 * 8);
     // blockIdx.y splits the batch into groups of frames: enough groups to fill the chip when there are few tiles,
-    // and never more than RIP_REMAP_FRAMES (4) frames per tile visit -- the workgroups in flight then work on the
-    // same few source frames (60 MB at 2448x2048: L2 / Infinity Cache resident, so the overlapping rectangles of
-    // neighbouring tiles are fetched once) and the dispatcher balances 16x more, smaller units.  Measured on
-    // config2, 64 frames: 64 frames per visit 0.61 ms, 8: 0.57, 4: 0.54, 2: 0.58, 1: 0.71.
-    const int frames_per_visit = std::max(1, tn.remap_frames);
+    // and a bounded number of frames per tile visit (RIP_REMAP_FRAMES) -- the workgroups in flight then work on the
+    // same few source frames (L2 / Infinity Cache resident, so the overlapping rectangles of neighbouring tiles are
+    // fetched once) and the dispatcher balances many more, smaller units.  Measured on config2, 64 frames: 64 frames per
+    // visit 0.61 ms, 8: 0.57, 4: 0.54, 2: 0.58, 1: 0.71.  Round 3, 256 frames, ms per launch at 3 / 4 / 6 / 8 / 12 / 16 frames
+    // per visit: 3840x2160 3.35 / 3.22 / 3.17 / 3.16 / 3.21 / 3.31; 2448x2048 2.05 / 2.02 / 2.08 / 2.19 / 2.31 / 2.39; 1920x1200
+    // 1.00 / 0.96 / 0.90 / 0.88 / 0.87 / 0.88; 1440x1080 0.74 / 0.71 / 0.67 / 0.65 / 0.64 / 0.64 -- the best count keeps the
+    // source frames of a visit near 64 MB, so that is the default rule (4 .. 12 frames).
+    int frames_per_visit = tn.remap_frames;
+    if (frames_per_visit <= 0) {
+      const unsigned long long frame_bytes = (unsigned long long)b.src_step * (unsigned long long)b.rows;
+      frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(4, ((64ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
+    }
     int groups = std::max((256 * per_cu) / blocks, (b.n_frames + frames_per_visit - 1) / frames_per_visit);
     groups = std::max(1, std::min(b.n_frames, groups));
     const dim3 grid(blocks, groups);
