@@ -615,7 +615,8 @@ __device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, 
     h = r - g + 4 * diff;
   h = (mul24(h, tb.hdiv(diff)) + (1 << 11)) >> 12;
   h += h < 0 ? 180 : 0;
-  h = clampi(h, 0, 255);
+  // saturate_cast<uchar>(h) of RGB2HSV_b is dead: the numerator is within [-diff, 5 diff], so the scaled value is within
+  // [-30, 150] and the wrapped one within [0, 179] (tests/test_oracle_known_answers.py::test_hsv_hue_needs_no_saturation)
   // cv::multiply(hsv, Scalar(gains)): saturate_cast<uchar>(float(x) * gain) per channel, then back to float for HSV2RGB_f.
   // A gain of exactly 1 leaves the 8-bit value as it is (h, s, v are already in [0, 255]), so the multiply and the two
   // conversions of such a channel can be skipped: UNIT names those channels at compile time (the caller branches once per
@@ -634,7 +635,9 @@ __device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, 
   // subtract pairs, three min/max with the free [0, 1] output clamp.  With s == 0 every channel is v * 1 = v exactly, which
   // is OpenCV's early-out.
   fh = fh * (6.f / 180.f);
-  fh = fh >= 6.f ? fh - 6.f : fh;  // fmod(h, 6): h <= 255/30 < 12, and h >= 0, so sector is always in [0, 5]
+  // fmod(h, 6): h <= 255/30 < 12, and h >= 0, so sector is always in [0, 5].  With a hue gain of exactly 1 the 8-bit hue is
+  // below 180 (above) and 179 * (6.f / 180.f) < 6: nothing to wrap
+  if constexpr (!(UNIT & 1u)) fh = fh >= 6.f ? fh - 6.f : fh;
   const float wb = max_sat(3.f - fh, fh - 5.f);
   const float wg = max_sat(1.f - fh, fh - 3.f);
   const float wr = min_sat(fh - 1.f, 5.f - fh);

@@ -459,6 +459,26 @@ def test_lab_8bit_tracks_the_float_cie_formulas(oracle):
     assert np.median(err) <= 1 and np.percentile(err, 99) <= 6 and (err == 0).mean() > 0.45
 
 
+def test_hsv_hue_needs_no_saturation(oracle):
+    """rip_device.hpp apply_hsv drops RGB2HSV_b's saturate_cast<uchar> of the hue and, for a hue gain of exactly 1, the
+    fmod(h, 6) of the inverse: for every chroma `diff` and every numerator the three branches can produce ([-diff, diff],
+    [diff, 3 diff], [3 diff, 5 diff]) the scaled, wrapped hue is within [0, 179], and float32(179) * (6.f / 180.f) < 6.
+    The oracle's own RGB2HSV_b over all 2^24 colours agrees."""
+    hdiv = oracle.table("hdiv180").astype(np.int64)
+    assert len(hdiv) == 256 and hdiv[0] == 0
+    lo, hi = 0, 0
+    for diff in range(256):
+        n = np.arange(-diff, 5 * diff + 1, dtype=np.int64)
+        h = (n * hdiv[diff] + (1 << 11)) >> 12
+        h = h + np.where(h < 0, 180, 0)
+        lo, hi = min(lo, int(h.min())), max(hi, int(h.max()))
+    assert (lo, hi) == (0, 179)
+    assert np.float32(179) * (np.float32(6.0) / np.float32(180.0)) < np.float32(6.0)
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=-1).astype(np.uint8).reshape(4096, 4096, 3)
+    assert int(oracle.bgr2hsv(img)[..., 0].max()) == 179
+
+
 def test_hsv_8bit_tracks_the_float_formulas(oracle):
     import colorsys
     rng = np.random.default_rng(12)
