@@ -170,6 +170,13 @@ __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb&
     if constexpr ((BITS & ST_HSV) == 0) return invg_pack4(out_idx);
     invg_values4(out_idx, q);
   } else {
+    if constexpr ((BITS & ST_CC) != 0 && (BITS & (ST_GAMMA | ST_HSV)) == 0) {
+      // the colour matrix is the last stage: its results are converted straight into their place in the packed output
+      float of[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) apply_cc_f(p, cc, q[k][0], q[k][1], q[k][2], of[k]);
+      return pack4_from_floats(of);
+    }
     if constexpr ((BITS & ST_CC) != 0) {
 #pragma unroll
       for (int k = 0; k < 4; k++) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
@@ -182,16 +189,18 @@ __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb&
     }
   }
   if constexpr ((BITS & ST_HSV) != 0) {
+    float of[4][3];
     if (hr.unit == 5u) {  // hue and value gains are 1 (the usual configuration scales the saturation only)
       keep_branch();
 #pragma unroll
-      for (int k = 0; k < 4; k++) apply_hsv<5u>(hr.g, tb, q[k][0], q[k][1], q[k][2]);
+      for (int k = 0; k < 4; k++) apply_hsv_f<5u>(hr.g, tb, q[k][0], q[k][1], q[k][2], of[k]);
     } else {
       asm volatile("s_nop 0 ; rip_generic_hsv_gains");  // marks the block for tools/chain_ledger.py (bench runs take the other one)
 #pragma unroll
-      for (int k = 0; k < 4; k++) apply_hsv<0u>(hr.g, tb, q[k][0], q[k][1], q[k][2]);
+      for (int k = 0; k < 4; k++) apply_hsv_f<0u>(hr.g, tb, q[k][0], q[k][1], q[k][2], of[k]);
       asm volatile("s_nop 0 ; rip_generic_hsv_end");
     }
+    return pack4_from_floats(of);
   }
   return pack4(q);
 }

@@ -601,11 +601,14 @@ __device__ __forceinline__ float min_sat(float a, float b) {
 // color_enhancer.cpp:38-47: RGB2HSV_b (H in [0,180)), float gain with u8 saturation,
 // HSV2RGB_b (float)
 // UNIT: compile-time set of channels whose gain is exactly 1 (bit c: channel c of H, S, V)
+// apply_hsv_f: the three results before their saturate_cast<uchar> (the fast kernel converts them straight into their place
+// in the packed output: v_cvt_pk_u8_f32 inserts its byte into a given dword)
 template <unsigned UNIT = 0u, typename Tabs>
-__device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, int& b, int& g, int& r) {
+__device__ __forceinline__ void apply_hsv_f(const float (&hg)[3], const Tabs& tb, int b, int g, int r, float (&out)[3]) {
   int v = max(b, max(g, r)), vmin = min(b, min(g, r));
   int diff = v - vmin;
   int s = (mul24(diff, tb.sdiv(v)) + (1 << 11)) >> 12;
+  // (both candidates computed and selected with v_cndmask instead of the branches hipcc makes of this: 0.896 against 0.888 ms)
   int h;
   if (v == r)
     h = g - b;
@@ -644,9 +647,25 @@ __device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, 
   const float ob = fv * (1.f - fs * wb);
   const float og = fv * (1.f - fs * wg);
   const float orr = fv * (1.f - fs * wr);
-  b = sat_round_u8(ob * 255.f);
-  g = sat_round_u8(og * 255.f);
-  r = sat_round_u8(orr * 255.f);
+  out[0] = ob * 255.f;
+  out[1] = og * 255.f;
+  out[2] = orr * 255.f;
+}
+template <unsigned UNIT = 0u, typename Tabs>
+__device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, int& b, int& g, int& r) {
+  float o[3];
+  apply_hsv_f<UNIT>(hg, tb, b, g, r, o);
+  b = sat_round_u8(o[0]);
+  g = sat_round_u8(o[1]);
+  r = sat_round_u8(o[2]);
+}
+// saturate_cast<uchar> of twelve floats (four pixels x B, G, R) straight into 12 interleaved bytes: v_cvt_pk_u8_f32 writes
+// its result into byte `sel` of the dword it is given, so no shift / or merges the bytes afterwards
+__device__ __forceinline__ Pack3 pack4_from_floats(const float (&f)[4][3]) {
+  uint32_t d[3] = {0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < 12; j++) d[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(f[j / 3][j % 3], j & 3, d[j >> 2]);
+  return Pack3{d[0], d[1], d[2]};
 }
 
 // The pointwise chain after flip.  BITS >= 0: compile-time stage set; BITS < 0: runtime.
