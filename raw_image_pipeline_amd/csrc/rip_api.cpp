@@ -159,6 +159,7 @@ struct rip_pipeline {
   // environment overrides, read once when the handle is created (never on a frame path)
   rip::Tunables tn;
   bool maps_on_host = false;      // RIP_MAPS_ON_HOST
+  bool plan_on_host = false;      // RIP_PLAN_ON_HOST: compile the remap plan on the host even when the maps are on the device
   std::string debug_dir = "/tmp"; // RIP_DEBUG_DIR
   std::string ccc_model_env;      // RIP_CCC_MODEL
   mutable std::string last_error;
@@ -172,6 +173,7 @@ struct rip_pipeline {
   std::vector<float> h_map;
   DevBuf d_map;
   bool map_dirty = true, map_uploaded = false;
+  bool h_map_valid = false;  // device-built maps are copied to the host only when something on the host asks for them
   // vignetting mask plane per geometry (float, rows x cols)
   std::vector<float> h_vig;
   DevBuf d_vig;
@@ -187,8 +189,10 @@ struct rip_pipeline {
   DevBuf d_stats, d_wb, d_hist, d_work, d_rowbest, d_argmax, d_mid;
   // compiled remap plan (tiled LDS gather), rebuilt when the maps or the source geometry change
   rip::RemapPlan plan;
-  DevBuf d_plan_words, d_plan_tiles, d_plan_border;
+  DevBuf d_plan_words, d_plan_tiles, d_plan_border, d_plan_counters;
   bool plan_uploaded = false;
+  bool plan_on_device = false;  // compiled by remap_plan_kernel: plan.words / tiles / border stay empty on the host
+  int plan_n_border = 0;
   bool use_tiled_remap = true;
   int last_batch_frames = 0;
   // prefix of d_stats known to hold zeroed FrameStats records (the grey-world / pca statistics kernels clean up after themselves)
@@ -227,7 +231,7 @@ struct rip_pipeline {
     if (dl_stream) (void)hipStreamDestroy(dl_stream);
     for (DevBuf* b : {&d_tabs, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
                       &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col, &d_vig, &d_plan_words,
-                      &d_plan_tiles, &d_plan_border, &d_dbg})
+                      &d_plan_tiles, &d_plan_border, &d_plan_counters, &d_dbg})
       b->release();
   }
 };
@@ -292,18 +296,29 @@ void ensure_host_maps(rip_pipeline* p) {
     p->d_map.reserve(n * sizeof(float));
     fp.map_xy = p->d_map.as<float>();
     rip::launch_fisheye_maps(fp, p->stream);
-    // the host copy feeds the remap-plan compiler and rip_get_undistortion_maps
-    HIP_CHECK(hipMemcpyAsync(p->h_map.data(), p->d_map.ptr, n * sizeof(float), hipMemcpyDeviceToHost, p->stream));
-    HIP_CHECK(hipStreamSynchronize(p->stream));
+    // no host copy yet: the remap-plan compiler runs on the device too; need_host_map() fetches the floats for
+    // rip_get_undistortion_maps or for a plan compiled on the host
     p->map_dirty = false;
     p->map_uploaded = true;
+    p->h_map_valid = false;
     p->plan.valid = false;
     return;
   }
   rip::fisheye_init_undistort_rectify_map(m.dist_K, m.dist_D, m.dist_R, m.rect_K, m.dist_w, m.dist_h, p->h_map.data());
   p->map_dirty = false;
   p->map_uploaded = false;
+  p->h_map_valid = true;
   p->plan.valid = false;
+}
+
+// the maps as floats on the host
+void need_host_map(rip_pipeline* p) {
+  ensure_host_maps(p);
+  if (p->h_map_valid) return;
+  DeviceGuard device_guard(p->device);
+  HIP_CHECK(hipMemcpyAsync(p->h_map.data(), p->d_map.ptr, p->h_map.size() * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+  HIP_CHECK(hipStreamSynchronize(p->stream));
+  p->h_map_valid = true;
 }
 
 void ensure_maps(rip_pipeline* p);
@@ -316,8 +331,59 @@ void ensure_plan(rip_pipeline* p, int src_rows, int src_cols) {
   const rip::Modules& m = p->m;
   if (!p->plan.valid || p->plan.src_rows != src_rows || p->plan.src_cols != src_cols || p->plan.drows != m.dist_h ||
       p->plan.dcols != m.dist_w) {
-    rip::compile_remap_plan(p->plan, p->h_map.data(), m.dist_h, m.dist_w, src_rows, src_cols);
-    p->plan_uploaded = false;
+    p->plan_on_device = false;
+    if (maps_on_device(p) && !p->plan_on_host) {
+      // Compile the plan where the maps are (rip_maps.hip remap_plan_kernel: one workgroup per tile; the same words, tile
+      // rectangles and border pixels as rip::compile_remap_plan, the border list in another order): no 8 B/px map read-back,
+      // no 4 B/px plan upload, no host threads -- a calibration change costs the map kernel plus ~0.1 ms.
+      rip::RemapPlan& pl = p->plan;
+      pl = rip::RemapPlan();
+      pl.drows = m.dist_h;
+      pl.dcols = m.dist_w;
+      pl.src_rows = src_rows;
+      pl.src_cols = src_cols;
+      pl.tiles_x = (pl.dcols + rip::kRemapTileW - 1) / rip::kRemapTileW;
+      pl.tiles_y = (pl.drows + rip::kRemapTileH - 1) / rip::kRemapTileH;
+      const size_t ntiles = (size_t)pl.tiles_x * pl.tiles_y;
+      const unsigned border_cap = 1u << 20;  // pixels; more than that (a map that mostly straddles the border) goes to the host
+      p->d_plan_words.reserve(ntiles * rip::kRemapTilePx * sizeof(uint32_t));
+      p->d_plan_tiles.reserve(ntiles * sizeof(rip::RemapTileDesc));
+      p->d_plan_border.reserve((size_t)border_cap * sizeof(uint32_t));
+      p->d_plan_counters.reserve(4 * sizeof(unsigned));
+      HIP_CHECK(hipMemsetAsync(p->d_plan_counters.ptr, 0, 4 * sizeof(unsigned), p->stream));
+      rip::RemapPlanBuildParams bp = {};
+      bp.map_xy = p->d_map.as<float>();
+      bp.drows = pl.drows;
+      bp.dcols = pl.dcols;
+      bp.src_rows = src_rows;
+      bp.src_cols = src_cols;
+      bp.tiles_x = pl.tiles_x;
+      bp.tiles_y = pl.tiles_y;
+      bp.words = p->d_plan_words.as<uint32_t>();
+      bp.tiles = p->d_plan_tiles.as<rip::RemapTileDesc>();
+      bp.border = p->d_plan_border.as<uint32_t>();
+      bp.border_cap = border_cap;
+      bp.counters = p->d_plan_counters.as<unsigned>();
+      rip::launch_remap_plan_build(bp, p->stream);
+      unsigned counters[4] = {0, 0, 0, 0};
+      HIP_CHECK(hipMemcpyAsync(counters, p->d_plan_counters.ptr, sizeof(counters), hipMemcpyDeviceToHost, p->stream));
+      HIP_CHECK(hipStreamSynchronize(p->stream));
+      if (counters[0] <= border_cap) {
+        p->plan_n_border = (int)counters[0];
+        pl.max_lds_bytes = counters[1];
+        pl.max_rect_w = (int)counters[2];
+        pl.max_rect_h = (int)counters[3];
+        pl.valid = true;
+        p->plan_on_device = true;
+        p->plan_uploaded = true;
+      }
+    }
+    if (!p->plan_on_device) {
+      need_host_map(p);
+      rip::compile_remap_plan(p->plan, p->h_map.data(), m.dist_h, m.dist_w, src_rows, src_cols);
+      p->plan_n_border = (int)p->plan.border.size();
+      p->plan_uploaded = false;
+    }
   }
   if (!p->plan_uploaded) {
     p->d_plan_words.reserve(p->plan.words.size() * sizeof(uint32_t));
@@ -830,7 +896,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
         tp.tiles_x = p->plan.tiles_x;
         tp.tiles_y = p->plan.tiles_y;
         tp.border_list = p->d_plan_border.as<uint32_t>();
-        tp.n_border = (int)p->plan.border.size();
+        tp.n_border = p->plan_n_border;
         tp.lds_bytes = (unsigned)p->plan.max_lds_bytes;
         ProfScope ps(p, RIP_KERNEL_REMAP, back);
         done = rip::launch_remap_tiled(tp, p->tn, back);
@@ -1025,6 +1091,7 @@ rip_status rip_create(int device, int use_gpu, const char* params_path, const ch
     p->tn = rip::tunables_from_env();
     if (const char* t = std::getenv("RIP_REMAP_TILED")) p->use_tiled_remap = std::atoi(t) != 0;
     if (const char* e = std::getenv("RIP_MAPS_ON_HOST")) p->maps_on_host = *e && *e != '0';
+    if (const char* e = std::getenv("RIP_PLAN_ON_HOST")) p->plan_on_host = *e && *e != '0';
     if (const char* e = std::getenv("RIP_DEBUG_DIR")) if (*e) p->debug_dir = e;
     if (const char* e = std::getenv("RIP_CCC_MODEL")) if (*e) p->ccc_model_env = e;
     if (!p->ccc_model_env.empty()) rip::ccc_load_model_file(p->ccc, p->ccc_model_env);
@@ -1551,7 +1618,7 @@ rip_status rip_get_undistortion_maps(rip_pipeline* p, float* map_x, float* map_y
     if (rows) *rows = p->m.dist_h;
     if (cols) *cols = p->m.dist_w;
     if (!map_x || !map_y) return;
-    ensure_host_maps(p);
+    need_host_map(p);
     size_t n = (size_t)p->m.dist_w * p->m.dist_h;
     if (cap < n) throw CapacityError("map buffers too small");
     for (size_t i = 0; i < n; i++) {

@@ -191,6 +191,22 @@ struct FisheyeMapParams {
 void launch_fisheye_maps(const FisheyeMapParams& p, hipStream_t stream);
 void launch_atan_probe(const double* in, double* out, int n, hipStream_t stream);  // test hook: the kernel's atan
 
+// Remap-plan compiler on the device (host counterpart and format: rip_host.cpp compile_remap_plan): one workgroup per
+// destination tile turns the float2 map into the tile's source rectangle and its 1024 plan words; pixels whose taps
+// straddle the source border are appended to `border` (any order).  counters: [0] border pixels found (may exceed
+// border_cap: the caller then falls back to the host compiler), [1] largest LDS footprint of a tile's rectangle in bytes
+// (remap_tile_lds_bytes), [2] / [3] largest rectangle width / height.  counters must be zeroed before the launch.
+struct RemapPlanBuildParams {
+  const float* map_xy;  // [drows][dcols] interleaved (x, y)
+  int drows, dcols, src_rows, src_cols, tiles_x, tiles_y;
+  uint32_t* words;      // [tiles][kRemapTilePx]
+  RemapTileDesc* tiles; // [tiles]
+  uint32_t* border;     // [border_cap] (yd << 16 | xd)
+  unsigned border_cap;
+  unsigned* counters;   // [4]
+};
+void launch_remap_plan_build(const RemapPlanBuildParams& p, hipStream_t stream);
+
 // Launch tunables.  The defaults are the measured optima; the environment variables named beside them
 // override them for experiments, and are read ONCE, by tunables_from_env() when a handle is created -- never on a launch path.
 struct Tunables {

@@ -179,6 +179,32 @@ def test_undistortion_batch_through_the_lds_ring(gpu_pipe, oracle, monkeypatch, 
         assert_images_equal(out[i], ref, "ring frame %d (fov %g, %d stages)" % (i, fov, stages))
 
 
+@pytest.mark.parametrize("size,balance,fov", [((2448, 2048), 0.0, 1.0), ((1920, 1200), 1.0, 0.8), ((450, 270), 0.5, 3.6), ((131, 97), 1.0, 0.6)])
+def test_remap_plan_compiled_on_the_device_equals_the_host_plan(rip_lib, oracle, monkeypatch, size, balance, fov):
+    """The remap plan (tile rectangles, 4-byte plan words, border pixels) is compiled on the device, where the maps are
+    (rip_maps.hip remap_plan_kernel); RIP_PLAN_ON_HOST=1 keeps rip_host.cpp's compiler.  Both handles must produce the same
+    image -- geometries with many border pixels (balance 1: the rectified image reaches beyond the source), rectangles too
+    wide for the ring (fov 3.6), a partial last tile column and row -- and the oracle's, and hand out the same maps."""
+    from raw_image_pipeline_amd import RawImagePipeline
+    w, h = size
+    frame = synth.gen_frame(w, h, "bayer_gbrg8", seed=77, kind="uniform")
+    c = cfg(undistort=True, cam=synth.camera_model(w, h), balance=balance, fov_scale=fov)
+    dev = RawImagePipeline(False, "", "", "", device=0)
+    configure(dev, c)
+    got_dev = dev.process(frame, "bayer_gbrg8")
+    monkeypatch.setenv("RIP_PLAN_ON_HOST", "1")
+    host = RawImagePipeline(False, "", "", "", device=0)
+    configure(host, c)
+    got_host = host.process(frame, "bayer_gbrg8")
+    assert_images_equal(got_dev, got_host, "device plan vs host plan %s" % (size,))
+    mx_d, my_d = dev.get_undistortion_maps()
+    mx_h, my_h = host.get_undistortion_maps()
+    assert np.array_equal(mx_d, mx_h) and np.array_equal(my_d, my_h)
+    if w * h <= 1920 * 1200:
+        ref, _ = oracle_run(oracle, c, frame, "bayer_gbrg8")
+        assert_images_equal(got_dev, ref, "device plan vs oracle %s" % (size,))
+
+
 @pytest.mark.parametrize("angle", [90, 270])
 @pytest.mark.parametrize("size,pattern", [((160, 120), "bayer_rggb8"), ((152, 100), "bayer_grbg8"), ((264, 130), "bayer_bggr8")])
 def test_full_chain_with_quarter_turn_flips(gpu_pipe, oracle, angle, size, pattern):
