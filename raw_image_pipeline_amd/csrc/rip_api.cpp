@@ -167,7 +167,7 @@ struct rip_pipeline {
 
   // constants on the device
   rip::DevTables h_tabs;
-  DevBuf d_tabs;
+  DevBuf d_tabs, d_vig_image;  // d_vig_image: the fused chain's LDS tables as one image (rip::launch_vig_image)
   bool tabs_dirty = true;
   // undistortion maps (interleaved float2), built lazily
   std::vector<float> h_map;
@@ -229,7 +229,7 @@ struct rip_pipeline {
     for (auto& sl : ring) sl->release();
     if (ul_stream) (void)hipStreamDestroy(ul_stream);
     if (dl_stream) (void)hipStreamDestroy(dl_stream);
-    for (DevBuf* b : {&d_tabs, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
+    for (DevBuf* b : {&d_tabs, &d_vig_image, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
                       &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col, &d_vig, &d_plan_words,
                       &d_plan_tiles, &d_plan_border, &d_plan_counters, &d_dbg})
       b->release();
@@ -434,6 +434,8 @@ void ensure_tables(rip_pipeline* p) {
   rip::fft256_twiddles(t.tw_re, t.tw_im);
   p->d_tabs.reserve(sizeof(rip::DevTables));
   HIP_CHECK(hipMemcpyAsync(p->d_tabs.ptr, &t, sizeof(t), hipMemcpyHostToDevice, p->stream));
+  p->d_vig_image.reserve(rip::vig_image_bytes());
+  rip::launch_vig_image(p->d_tabs.as<rip::DevTables>(), p->d_vig_image.as<uint32_t>(), p->stream);
   if (!p->d_accum.ptr) {
     p->d_accum.reserve(accum.size() * sizeof(float));
     HIP_CHECK(hipMemcpyAsync(p->d_accum.ptr, accum.data(), accum.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
@@ -854,6 +856,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     c.hsv_gain[1] = (float)p->m.ce_saturation_gain;
     c.hsv_gain[2] = (float)p->m.ce_value_gain;
     c.tabs = p->d_tabs.as<rip::DevTables>();
+    c.vig_image = p->d_vig_image.as<uint32_t>();
     // overlap_mode 2: only the statistics of this group share the chip with the remap of the previous one; the chain waits
     if (back != front && p->tn.overlap_mode == 2 && g > 0) HIP_CHECK(hipStreamWaitEvent(front, p->ovl_events[groups + g - 1], 0));
     {

@@ -118,8 +118,13 @@ struct FastTabs {
     return 0;
   }
   template <int NT>
-  __device__ __forceinline__ void load(const DevTables* t) {
-    if constexpr (kVig) vig.v.template load<NT>(t);
+  __device__ __forceinline__ void load(const DevTables* t, const uint32_t* vig_image) {
+    if constexpr (kVig) {
+      if (vig_image)
+        vig.v.template load_image<NT>(vig_image);
+      else
+        vig.v.template load<NT>(t);
+    }
     if constexpr (kGamma)
       for (int i = threadIdx.x; i < 64; i += NT) reinterpret_cast<uint32_t*>(gam.v.lut)[i] = reinterpret_cast<const uint32_t*>(t->gamma_lut)[i];
     if constexpr (kHsv)
@@ -208,7 +213,7 @@ __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb&
 template <int BITS, int WB, int NT>
 __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
   __shared__ FastTabs<BITS> tb;
-  tb.template load<NT>(p.tabs);
+  tb.template load<NT>(p.tabs, p.vig_image);
   CcRegs cc = {};
   if constexpr ((BITS & ST_CC) != 0) cc.load(p);
   HsvRegs hr = {};
@@ -486,6 +491,15 @@ __global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int ti
 }
 
 
+// the LDS tables of the vignetting variants, built once with the table address left out (load_image adds the kernel's own)
+__global__ __launch_bounds__(512) void vig_image_kernel(const DevTables* tabs, uint32_t* image) {
+  __shared__ VigTabs t;
+  t.template load<512>(tabs, 0u);
+  __syncthreads();
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&t);
+  for (int i = threadIdx.x; i < (int)(sizeof(VigTabs) / 4); i += 512) image[i] = src[i];
+}
+
 template <int BITS, int WB>
 void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream, bool debug_occupancy) {
   constexpr int NT = fast_threads<BITS>();
@@ -560,6 +574,11 @@ static int frame_groups(const ChainParams& p, const Tunables& tn, int cap, int b
   const int frames_per_visit = tn.chain_frames > 0 ? tn.chain_frames : (valu_bound ? 16 : streaming);
   const int groups = std::max(cap / std::max(blocks, 1), (p.n_frames + frames_per_visit - 1) / frames_per_visit);
   return std::max(1, std::min(p.n_frames, groups));
+}
+
+size_t vig_image_bytes() { return sizeof(VigTabs); }
+void launch_vig_image(const DevTables* tabs, uint32_t* image, hipStream_t stream) {
+  hipLaunchKernelGGL(vig_image_kernel, dim3(1), dim3(512), 0, stream, tabs, image);
 }
 
 void launch_debayer16(const Debayer16Params& p, hipStream_t stream) {

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstddef>
 #include <cstdlib>
 
 namespace rip {
@@ -431,10 +432,41 @@ struct VigTabs {
   float2 cby[kVigCbrtN];
   int4 yf[256];
   uint8_t invg[kInvgExtN];
+  // the LDS address of a __shared__ object is the low half of its flat address
+  __device__ __forceinline__ unsigned invg_lds_address() const { return (unsigned)reinterpret_cast<uintptr_t>(&invg[0]); }
+  // A ready-made image of this struct (built once per table change by vig_image_kernel with invg_base = 0) copied with
+  // 16-byte loads, all of them in flight at once; the per-L' records get this kernel's LDS address of the table added to
+  // their three accumulators on the way.  Building the 54 KB from DevTables in every workgroup cost ~5 us of its ~90.
   template <int NT>
-  __device__ __forceinline__ void load(const DevTables* t) {
-    // the LDS address of a __shared__ object is the low half of its flat address
-    const unsigned invg_base = (unsigned)reinterpret_cast<uintptr_t>(&invg[0]);
+  __device__ __forceinline__ void load_image(const uint32_t* image) {
+    static_assert(sizeof(VigTabs) % 16 == 0, "copied as uint4");
+    constexpr int kVec = (int)(sizeof(VigTabs) / 16), kIter = (kVec + NT - 1) / NT;
+    const unsigned add = invg_lds_address() << 14;
+    const int yf0 = (int)(offsetof(VigTabs, yf) / 16);
+    const uint4* src = reinterpret_cast<const uint4*>(image);
+    uint4* dst = reinterpret_cast<uint4*>(this);
+    uint4 v[kIter];
+#pragma unroll
+    for (int k = 0; k < kIter; k++) {
+      const int i = (int)threadIdx.x + k * NT;
+      if (i < kVec) v[k] = src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kIter; k++) {
+      const int i = (int)threadIdx.x + k * NT;
+      if (i >= kVec) continue;
+      if (i >= yf0 && i < yf0 + 256) {
+        v[k].y += add;
+        v[k].z += add;
+        v[k].w += add;
+      }
+      dst[i] = v[k];
+    }
+  }
+  template <int NT>
+  __device__ __forceinline__ void load(const DevTables* t) { load<NT>(t, invg_lds_address()); }
+  template <int NT>
+  __device__ __forceinline__ void load(const DevTables* t, const unsigned invg_base) {
     for (int i = threadIdx.x; i < 256; i += NT) {
       lin[i] = (float)t->lin_tab[i];
       const uint32_t e = t->yf_tab[i];

@@ -99,6 +99,9 @@ struct ChainParams {
   const float* vig_mask;  // [drows][dcols] vignetting mask plane (vignetting_correction.cpp:32-63), ST_VIG only
   float hsv_gain[3];  // applied to H, S, V
   const DevTables* tabs;
+  // the LDS tables of the vignetting variants as one ready-made image (launch_vig_image): a workgroup copies it with 16-byte
+  // loads instead of rebuilding 54 KB of tables from DevTables; null: build them in the kernel
+  const uint32_t* vig_image;
 };
 
 // 16-bit Bayer extension (the reference lists bayer_*16 and rejects them, debayer.hpp:73-80 / debayer.cpp:76-78):
@@ -229,6 +232,9 @@ Tunables tunables_from_env();  // rip_api.cpp; called by rip_create
 bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream);
 void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream);
 void launch_debayer16(const Debayer16Params& p, hipStream_t stream);
+// builds the image ChainParams::vig_image points to (vig_image_bytes() bytes) from the handle's tables
+size_t vig_image_bytes();
+void launch_vig_image(const DevTables* tabs, uint32_t* image, hipStream_t stream);
 void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream);
 // Returns false when the histogram launch failed: nothing after it was enqueued and the caller must not run the
 // state-advancing finalisation on stale data.
