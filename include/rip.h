@@ -263,6 +263,10 @@ rip_status rip_get_vignetting_mask(rip_pipeline* p, int rows, int cols, float* o
 /* Test hook: the double-double atan the device map builder uses (rip_maps.hip), evaluated on the device for n doubles;
  * the parity tests compare it with libm's over the range fisheye maps reach. */
 rip_status rip_debug_atan(rip_pipeline* p, const double* in, double* out, int n);
+/* Test hook: the compiled remap plan of the current geometry (compiled now if it is not yet): info = {tiles_x, tiles_y,
+ * border pixels, largest LDS footprint of a tile's source rectangle in bytes, largest rectangle width, height, 1 if the
+ * plan was compiled on the device, tile width, tile height}.  Needs a loaded calibration and a device. */
+rip_status rip_debug_plan_info(rip_pipeline* p, int src_rows, int src_cols, int info[9]);
 /* Test hook for the debug dumps: writes image (rows x cols x channels bytes, channels 1 or 3 = BGR) to path as the PNG
  * writer of rip_set_debug does, after the reference's min-max normalisation when normalize != 0.  No device needed;
  * p may be NULL. */

@@ -1697,6 +1697,24 @@ rip_status rip_debug_write_png(rip_pipeline* p, const char* path, const uint8_t*
   });
 }
 
+rip_status rip_debug_plan_info(rip_pipeline* p, int src_rows, int src_cols, int info[9]) {
+  return guarded(p, [&] {
+    need_device(p);
+    if (!info) throw InvalidArgument("null info");
+    DeviceGuard device_guard(p->device);
+    ensure_plan(p, src_rows, src_cols);
+    info[0] = p->plan.tiles_x;
+    info[1] = p->plan.tiles_y;
+    info[2] = p->plan_n_border;
+    info[3] = (int)p->plan.max_lds_bytes;
+    info[4] = p->plan.max_rect_w;
+    info[5] = p->plan.max_rect_h;
+    info[6] = p->plan_on_device ? 1 : 0;
+    info[7] = rip::kRemapTileW;
+    info[8] = rip::kRemapTileH;
+  });
+}
+
 rip_status rip_debug_atan(rip_pipeline* p, const double* in, double* out, int n) {
   if (!p) return RIP_ERR_INVALID_ARGUMENT;
   return guarded(p, [&] {

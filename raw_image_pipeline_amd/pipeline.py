@@ -533,6 +533,13 @@ class RawImagePipeline:
         self._call("rip_get_white_balance_info", buf.ctypes.data_as(C.c_void_p), int(n_frames))
         return buf
 
+    def debug_plan_info(self, src_rows, src_cols):
+        """Test hook (rip_debug_plan_info): dict describing the compiled remap plan of the current calibration."""
+        info = (C.c_int * 9)()
+        self._call("rip_debug_plan_info", int(src_rows), int(src_cols), info)
+        keys = ("tiles_x", "tiles_y", "border_pixels", "max_lds_bytes", "max_rect_w", "max_rect_h", "on_device", "tile_w", "tile_h")
+        return dict(zip(keys, [int(v) for v in info]))
+
     def set_tunable(self, name, value):
         """Launch tunable of this handle (rip_set_tunable: development / test hook; the library reads its environment
         overrides once, when the handle is created)."""

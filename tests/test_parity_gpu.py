@@ -197,6 +197,12 @@ def test_remap_plan_compiled_on_the_device_equals_the_host_plan(rip_lib, oracle,
     configure(host, c)
     got_host = host.process(frame, "bayer_gbrg8")
     assert_images_equal(got_dev, got_host, "device plan vs host plan %s" % (size,))
+    # same plan: tile grid, number of border pixels, largest source rectangle (a device plan that lists interior pixels as
+    # border pixels gives the same image, only much slower)
+    info_d, info_h = dev.debug_plan_info(h, w), host.debug_plan_info(h, w)
+    assert info_d["on_device"] == 1 and info_h["on_device"] == 0
+    for key in ("tiles_x", "tiles_y", "border_pixels", "max_lds_bytes", "max_rect_w", "max_rect_h"):
+        assert info_d[key] == info_h[key], (key, info_d, info_h)
     mx_d, my_d = dev.get_undistortion_maps()
     mx_h, my_h = host.get_undistortion_maps()
     assert np.array_equal(mx_d, mx_h) and np.array_equal(my_d, my_h)
