@@ -362,6 +362,15 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
         float x = a == 0 ? s_state.st_x : s_state.st_y, pc = a == 0 ? s_state.p_x : s_state.p_y;
         const float kf_h = s_state.kf_h, kf_r = s_state.kf_r;
         int last = a == 0 ? s_state.uv_x : s_state.uv_y;
+        // The gain does not see the data: p -> p' depends on (h, r) only.  Two cases keep the IEEE division (a dozen
+        // dependent instructions on a single lane) out of most steps without changing a bit of the result:
+        //  * h == 0 -- the filter the reference's pipeline actually runs (the one-argument constructor
+        //    leaves a default cv::KalmanFilter) -- gives t2 = +0, k = +0 / r = +0, p' = p + 1 and x' = x + 0 * innov = x;
+        //  * otherwise the covariance runs into a fixed point of the float iteration after a few dozen frames, and from
+        //    then on recomputing k would reproduce the same value.
+        const bool degenerate = kf_h == 0.f && kf_r > 0.f;
+        bool steady = false;
+        float k = 0.f;
         for (int i = 0; i < n; i++) {
           const int z = s_raw[i][a];
           int o = z;
@@ -369,16 +378,23 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
             if (first) {
               first = false;
               x = (float)z;
+            } else if (degenerate) {
+              pc = pc + 1.0f;
+              o = (int)x;
             } else {
               // cv::KalmanFilter(2,2,0) predict + correct
               const float x_pre = x;
-              const float p_pre = pc + 1.0f;
-              const float t2 = kf_h * p_pre;
-              const float t3 = t2 * kf_h + kf_r;
-              const float k = t2 / t3;
+              if (!steady) {
+                const float p_pre = pc + 1.0f;
+                const float t2 = kf_h * p_pre;
+                const float t3 = t2 * kf_h + kf_r;
+                k = t2 / t3;
+                const float p_new = p_pre - k * t2;
+                steady = p_new == pc;
+                pc = p_new;
+              }
               const float innov = (float)z - kf_h * x_pre;
               x = x_pre + k * innov;
-              pc = p_pre - k * t2;
               o = (int)x;
             }
           }
