@@ -33,7 +33,7 @@ LDS_CYCLES = {"ds_read_b32": 2, "ds_read_b64": 2, "ds_read_b128": 4, "ds_read_u8
 
 def compile_listing(tmp):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
-             "-fno-slp-vectorize", "-D__HIP_PLATFORM_AMD__", "-x", "hip", "-c", os.path.join(ROOT, "raw_image_pipeline_amd", "csrc", "rip_chain.hip"),
+             "-fno-slp-vectorize", "-D__HIP_PLATFORM_AMD__", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-x", "hip", "-c", os.path.join(ROOT, "raw_image_pipeline_amd", "csrc", "rip_chain.hip"),
              "-save-temps", "-o", "chain.o"]
     subprocess.run(["/opt/rocm/bin/hipcc"] + flags, cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return os.path.join(tmp, "rip_chain-hip-amdgcn-amd-amdhsa-gfx950.s")
