@@ -171,7 +171,7 @@ struct rip_pipeline {
   bool tabs_dirty = true;
   // undistortion maps (interleaved float2), built lazily
   std::vector<float> h_map;
-  DevBuf d_map;
+  DevBuf d_map, d_map_ckpt;  // d_map_ckpt: scratch of the map kernels (row accumulators at every 32nd column)
   bool map_dirty = true, map_uploaded = false;
   bool h_map_valid = false;  // device-built maps are copied to the host only when something on the host asks for them
   // vignetting mask plane per geometry (float, rows x cols)
@@ -229,7 +229,7 @@ struct rip_pipeline {
     for (auto& sl : ring) sl->release();
     if (ul_stream) (void)hipStreamDestroy(ul_stream);
     if (dl_stream) (void)hipStreamDestroy(dl_stream);
-    for (DevBuf* b : {&d_tabs, &d_vig_image, &d_map, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
+    for (DevBuf* b : {&d_tabs, &d_vig_image, &d_map, &d_map_ckpt, &d_filter_fft, &d_bias_fft, &d_accum, &d_ccc_state, &d_geom, &d_stats, &d_wb,
                       &d_hist, &d_work, &d_rowbest, &d_argmax, &d_mid, &d_in, &d_out, &d_tap_deb, &d_tap_col, &d_vig, &d_plan_words,
                       &d_plan_tiles, &d_plan_border, &d_plan_counters, &d_dbg})
       b->release();
@@ -295,6 +295,8 @@ void ensure_host_maps(rip_pipeline* p) {
     fp.h = m.dist_h;
     p->d_map.reserve(n * sizeof(float));
     fp.map_xy = p->d_map.as<float>();
+    p->d_map_ckpt.reserve(rip::fisheye_ckpt_bytes(fp.w, fp.h));
+    fp.ckpt = p->d_map_ckpt.as<double>();
     rip::launch_fisheye_maps(fp, p->stream);
     // no host copy yet: the remap-plan compiler runs on the device too; need_host_map() fetches the floats for
     // rip_get_undistortion_maps or for a plan compiled on the host

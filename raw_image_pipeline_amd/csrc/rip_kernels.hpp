@@ -190,7 +190,9 @@ struct FisheyeMapParams {
   double K[9], D[4], iR[9];
   int w, h;
   float* map_xy;  // [h][w] interleaved (x, y)
+  double* ckpt;   // scratch: fisheye_ckpt_bytes(w, h) bytes -- the row accumulators (X, Y, W) at every 32nd column
 };
+size_t fisheye_ckpt_bytes(int w, int h);
 void launch_fisheye_maps(const FisheyeMapParams& p, hipStream_t stream);
 void launch_atan_probe(const double* in, double* out, int n, hipStream_t stream);  // test hook: the kernel's atan
 
