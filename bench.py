@@ -3,7 +3,9 @@
 and the CPU baseline beside it.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
-torch.distributed.run with one rank per GPU.  A step is one pass of the hot path over one batch of
+torch.distributed.run with one rank per GPU -- or called plainly, in which case it launches its N ranks itself
+(`self_launch`).  It never prints a line whose n_gpus differs from --gpus: fewer devices than ranks (RCCL) or a
+WORLD_SIZE that disagrees with --gpus is a non-zero exit.  A step is one pass of the hot path over one batch of
 synthetic frames that are already resident in HBM.  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 2448x2048
@@ -306,21 +308,46 @@ def hbm_probe(torch, nbytes=1 << 30, reps=10):
     return res
 
 
+def self_launch(n):
+    """Re-runs this very command under `torch.distributed.run` with one process per GPU on this node (the launch line of
+    the driver's contract; the reference's counterpart is one node per camera, raw_image_pipeline_node.launch:85).
+    Returns the launcher's exit code; rank 0 of the children prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the pipeline has no CPU execution path")
     # RIP_BENCH_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the multi-rank path on a 1-GPU box (ranks share
     # the device); the driver's runs use one rank per GPU over RCCL
     backend = os.environ.get("RIP_BENCH_BACKEND", "nccl")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the pipeline has no CPU execution path")
+    if backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        # never a silent single-GPU number under an N-GPU label
+        raise SystemExit("--gpus %d but this node shows %d GPU(s): one rank per GPU over RCCL needs %d devices "
+                         "(RIP_BENCH_BACKEND=gloo rehearses the multi-rank path with ranks sharing a device)"
+                         % (args.gpus, torch.cuda.device_count(), args.gpus))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` called plainly: launch the N ranks ourselves, exactly as the driver would
+        sys.exit(self_launch(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line's n_gpus must be the number of ranks that ran" % (args.gpus, world))
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     if world > 1:

@@ -12,6 +12,8 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <stdexcept>
 #include <fstream>
 
 using raw_image_pipeline::CameraRig;
@@ -66,21 +68,34 @@ int main(int argc, char** argv) {
     std::vector<Mat> frames;
     std::vector<std::string> enc((size_t)n_cam, "bayer_rggb8");
     for (int c = 0; c < n_cam; c++) frames.push_back(make_u8(h, w, 1));
-    std::vector<CameraRig::Result> last;
+    std::vector<CameraRig::Result> last, last_threaded;
     const auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < n_frames; f++) {
       for (int c = 0; c < n_cam; c++) fill_frame(frames[(size_t)c], 1000u * (uint32_t)c + (uint32_t)f + 1u);
-      last = rig.process(frames, enc);  // all cameras concurrently, each camera's frames in order
+      last = rig.process(frames, enc);  // all cameras overlapped from this thread (submit x N, collect x N), each camera's frames in order
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // the same stream once more through the threaded option (one worker per camera): identical images, rate for the record
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int f = 0; f < n_frames; f++) {
+      for (int c = 0; c < n_cam; c++) fill_frame(frames[(size_t)c], 1000u * (uint32_t)c + (uint32_t)f + 1u);
+      last_threaded = rig.processThreaded(frames, enc);
+    }
+    const double sec_threaded = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    for (int c = 0; c < n_cam; c++) {
+      const Mat &a = last[(size_t)c].image, &b = last_threaded[(size_t)c].image;
+      bool same = a.rows == b.rows && a.cols == b.cols && last[(size_t)c].encoding == last_threaded[(size_t)c].encoding;
+      for (int y = 0; same && y < a.rows; y++) same = std::memcmp(a.data + (size_t)y * a.step, b.data + (size_t)y * b.step, (size_t)a.cols * 3) == 0;
+      if (!same) throw std::runtime_error("camera " + std::to_string(c) + ": threaded and pipelined results differ");
+    }
     for (int c = 0; c < n_cam; c++) {
       const Mat& o = last[(size_t)c].image;
       std::ofstream out(prefix + std::to_string(c) + ".bin", std::ios::binary);
       for (int y = 0; y < o.rows; y++) out.write(reinterpret_cast<const char*>(o.data + (size_t)y * o.step), (std::streamsize)o.cols * 3);
       std::printf("camera %d on device %d: %dx%d %s\n", c, rig.deviceOf(c), o.cols, o.rows, last[(size_t)c].encoding.c_str());
     }
-    std::printf("camera rig OK: %d cameras x %d frames in %.3f s (%.1f frames/s, host frames incl. generation)\n", n_cam, n_frames, sec,
-                n_cam * n_frames / sec);
+    std::printf("camera rig OK: %d cameras x %d frames in %.3f s (%.1f frames/s pipelined, %.1f frames/s threaded; host frames incl. generation)\n",
+                n_cam, n_frames, sec, n_cam * n_frames / sec, n_cam * n_frames / sec_threaded);
   } catch (const std::exception& e) {
     std::printf("FAIL: %s\n", e.what());
     return 1;

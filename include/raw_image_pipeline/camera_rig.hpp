@@ -5,14 +5,20 @@
 //
 // Sharding rule: camera c lives on devices[c % devices.size()] for its whole life -- its parameters,
 // undistortion plan, vignetting plane and ccc Kalman state are resident there -- and cameras never exchange data: there is
-// no collective on the data path, only independent streams.  Every camera owns one RawImagePipeline and one worker thread;
-// the frames of one camera are processed strictly in order, different cameras concurrently (their HIP work is enqueued from
-// different threads on different handles, so uploads, kernels and downloads of different cameras overlap on one device and
-// run fully in parallel on different devices).
+// no collective on the data path, only independent streams.  Every camera owns one RawImagePipeline; the frames of one camera
+// are processed strictly in order, different cameras concurrently.
+//
+// How the cameras overlap: process() submits every camera's frame from the calling thread (RawImagePipeline::submit =
+// rip_submit: upload, kernels and download are only enqueued, on that camera's own streams) and then collects them in camera
+// order -- camera c's download runs while camera c + 1 uploads and computes, on one device or on several, without a single
+// thread hand-over.  The round-3 shape, one worker thread per camera around the synchronous process(), is kept as
+// processThreaded() / submit(): measured on the GPU box it LOSES to plain sequential calls at small frames (4 cameras
+// 640x480: 1 613 vs 3 708 frames/s -- the wake-ups cost more than the overlap gives), so it is an option, not the default.
 #pragma once
 
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <future>
 #include <mutex>
@@ -41,9 +47,7 @@ class CameraRig {
       cams_.emplace_back(new Camera(use_gpu, params_path, calibration_path, color_calibration_path, dev));
     }
   }
-  ~CameraRig() {
-    for (auto& c : cams_) c->stop();
-  }
+  ~CameraRig() = default;  // every Camera joins its own worker
   CameraRig(const CameraRig&) = delete;
   CameraRig& operator=(const CameraRig&) = delete;
 
@@ -53,14 +57,40 @@ class CameraRig {
   // camera are queued in the rig (a RawImagePipeline is not re-entrant, like the reference's).
   RawImagePipeline& camera(int c) { return cams_.at((size_t)c)->pipe; }
 
-  // Queues one frame of `camera`; the future delivers the processed image and the rewritten encoding (or rethrows what
-  // apply() would have thrown).  `image` must stay valid until then.
+  // One frame per camera, all cameras overlapped from THIS thread (rip_submit x N, then rip_collect x N in camera order);
+  // returns when every camera is done.  frames.size() == size().  An exception of one camera (a bad encoding, say) is
+  // rethrown after the frames already in flight have been collected, so no ticket is left behind.
+  std::vector<Result> process(const std::vector<Mat>& frames, const std::vector<std::string>& encodings) {
+    if ((int)frames.size() != size() || (int)encodings.size() != size()) throw std::invalid_argument("CameraRig::process: one frame and one encoding per camera");
+    std::vector<uint64_t> tickets((size_t)size(), 0);
+    std::vector<Result> out((size_t)size());
+    std::exception_ptr failed;
+    int sent = 0;
+    try {
+      for (; sent < size(); sent++) tickets[(size_t)sent] = cams_[(size_t)sent]->pipe.submit(frames[(size_t)sent], encodings[(size_t)sent]);
+    } catch (...) {
+      failed = std::current_exception();
+    }
+    for (int c = 0; c < sent; c++) {
+      try {
+        out[(size_t)c].encoding = encodings[(size_t)c];
+        out[(size_t)c].image = cams_[(size_t)c]->pipe.collect(tickets[(size_t)c], out[(size_t)c].encoding);
+      } catch (...) {
+        if (!failed) failed = std::current_exception();
+      }
+    }
+    if (failed) std::rethrow_exception(failed);
+    return out;
+  }
+
+  // The threaded option: queues one frame of `camera` on that camera's worker thread (started on first use); the future
+  // delivers the processed image and the rewritten encoding (or rethrows what apply() would have thrown).  The Mat header
+  // is captured by value (reference-counted, like cv::Mat): the pixel memory must stay valid until then, the header not.
   std::future<Result> submit(int camera, const Mat& image, const std::string& encoding) {
     return cams_.at((size_t)camera)->enqueue(image, encoding);
   }
-  // One frame per camera, all cameras concurrently; returns when every camera is done.  frames.size() == size().
-  std::vector<Result> process(const std::vector<Mat>& frames, const std::vector<std::string>& encodings) {
-    if ((int)frames.size() != size() || (int)encodings.size() != size()) throw std::invalid_argument("CameraRig::process: one frame and one encoding per camera");
+  std::vector<Result> processThreaded(const std::vector<Mat>& frames, const std::vector<std::string>& encodings) {
+    if ((int)frames.size() != size() || (int)encodings.size() != size()) throw std::invalid_argument("CameraRig::processThreaded: one frame and one encoding per camera");
     std::vector<std::future<Result>> pending;
     for (int c = 0; c < size(); c++) pending.push_back(submit(c, frames[(size_t)c], encodings[(size_t)c]));
     std::vector<Result> out;
@@ -78,11 +108,13 @@ class CameraRig {
     std::deque<std::function<void()>> jobs;
     bool quit = false;
 
-    Camera(bool use_gpu, const std::string& a, const std::string& b, const std::string& c, int dev) : pipe(use_gpu, a, b, c, dev), device(dev) {
-      worker = std::thread([this] { run(); });
-    }
+    Camera(bool use_gpu, const std::string& a, const std::string& b, const std::string& c, int dev) : pipe(use_gpu, a, b, c, dev), device(dev) {}
+    // a Camera destroyed with its worker still joinable (a later camera's constructor threw) would end in std::terminate
+    ~Camera() { stop(); }
+    Camera(const Camera&) = delete;
+    Camera& operator=(const Camera&) = delete;
     std::future<Result> enqueue(const Mat& image, const std::string& encoding) {
-      auto task = std::make_shared<std::packaged_task<Result()>>([this, &image, encoding] {
+      auto task = std::make_shared<std::packaged_task<Result()>>([this, image, encoding] {
         Result r;
         r.encoding = encoding;
         r.image = pipe.process(image, r.encoding);
@@ -91,6 +123,7 @@ class CameraRig {
       std::future<Result> f = task->get_future();
       {
         std::lock_guard<std::mutex> lk(m);
+        if (!worker.joinable()) worker = std::thread([this] { run(); });  // the threaded mode pays for its thread only when used
         jobs.emplace_back([task] { (*task)(); });
       }
       cv.notify_one();

@@ -110,8 +110,9 @@ rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, s
  * Frames are processed in submission order (the ccc Kalman state advances frame by frame, exactly as with rip_apply).
  * The handle owns `depth` frame slots (rip_set_ring_depth, default 3, 1..16): with all of them in flight one more
  * rip_submit fails with RIP_ERR_CAPACITY and changes nothing.  A pageable `image` is read before rip_submit returns
- * (the HIP runtime pins and copies); memory from rip_host_alloc() is read asynchronously and must stay untouched until
- * the frame's rip_collect().  Debug dumps (rip_set_debug) are written by rip_apply only. */
+ * (the library copies it into a pinned staging buffer of the frame's slot -- it does not rely on what the HIP runtime does
+ * with an asynchronous copy from pageable memory); pinned memory (rip_host_alloc(), hipHostMalloc, hipHostRegister) is read
+ * asynchronously, with no staging copy, and must stay untouched until the frame's rip_collect().  Debug dumps (rip_set_debug) are written by rip_apply only. */
 rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step,
                       const char* encoding, uint64_t* ticket);
 /* Waits for the frame of `ticket` (tickets of one handle may be collected in any order) and hands over the result:
@@ -134,6 +135,12 @@ void rip_host_free(void* ptr);
  * rect_mask_ (undistortion.cpp:150-152). */
 rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_capacity, int* rows, int* cols,
                          int* channels);
+/* The same image without a copy, for frames that came through rip_collect: the taps the mask keeps are downloaded
+ * together with the result, so after rip_collect *view points into the handle's pinned host memory (valid as long as the
+ * rip_collect view: until the next rip_collect on the handle or until a rip_submit takes the slot).  *view is NULL -- with
+ * the geometry still reported -- when the image only exists on the device (frames of rip_apply): use rip_get_image then.
+ * hpp:134-137 (getDistDebayeredImage / getDistColorImage / getProcessedImage return Mat headers, no copy either). */
+rip_status rip_get_image_view(rip_pipeline* p, int which, const uint8_t** view, int* rows, int* cols, int* channels);
 /* Which taps rip_apply materialises (default: all three, as the reference does). */
 rip_status rip_set_taps(rip_pipeline* p, int tap_mask);
 

@@ -124,6 +124,10 @@ struct RingSlot {
   DevBuf d_in, d_out, d_tap_deb, d_tap_col;
   void* h_out = nullptr;  // hipHostMalloc
   size_t h_out_cap = 0;
+  void* h_in = nullptr;   // hipHostMalloc: staging copy of a pageable caller frame (the caller's buffer is free again when rip_submit returns)
+  size_t h_in_cap = 0;
+  void* h_tap[2] = {nullptr, nullptr};  // hipHostMalloc: the debayered / colour taps of the frame, downloaded with the result
+  size_t h_tap_cap[2] = {0, 0};
   hipEvent_t ev_up = nullptr, ev_kernels = nullptr, ev_done = nullptr;
   uint64_t ticket = 0;
   bool busy = false;  // submitted, not collected yet
@@ -138,10 +142,27 @@ struct RingSlot {
     HIP_CHECK(hipHostMalloc(&h_out, bytes + bytes / 8, hipHostMallocDefault));
     h_out_cap = bytes + bytes / 8;
   }
+  static void reserve_pinned(void*& ptr, size_t& cap, size_t bytes) {
+    if (bytes <= cap) return;
+    if (ptr) HIP_CHECK(hipHostFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    HIP_CHECK(hipHostMalloc(&ptr, bytes + bytes / 8, hipHostMallocDefault));
+    cap = bytes + bytes / 8;
+  }
+  void reserve_host_in(size_t bytes) { reserve_pinned(h_in, h_in_cap, bytes); }
   void release() {
     if (h_out) (void)hipHostFree(h_out);
     h_out = nullptr;
     h_out_cap = 0;
+    if (h_in) (void)hipHostFree(h_in);
+    h_in = nullptr;
+    h_in_cap = 0;
+    for (int i = 0; i < 2; i++) {
+      if (h_tap[i]) (void)hipHostFree(h_tap[i]);
+      h_tap[i] = nullptr;
+      h_tap_cap[i] = 0;
+    }
     for (hipEvent_t* e : {&ev_up, &ev_kernels, &ev_done}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
@@ -217,6 +238,7 @@ struct rip_pipeline {
   int last_rows[3] = {0, 0, 0}, last_cols[3] = {0, 0, 0}, last_cn[3] = {0, 0, 0};
   bool last_valid[3] = {false, false, false};
   DevBuf* last_buf[3] = {nullptr, nullptr, nullptr};
+  const void* last_host[3] = {nullptr, nullptr, nullptr};  // pinned host copy of the image (frames that came through rip_collect), else null
 
   ~rip_pipeline() {
     if (device < 0) return;
@@ -1237,6 +1259,7 @@ rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, 
     auto remember = [&](int which, DevBuf* buf, int r, int c, bool on) {
       p->last_valid[which] = on;
       p->last_buf[which] = buf;
+      p->last_host[which] = nullptr;
       p->last_rows[which] = r;
       p->last_cols[which] = c;
       p->last_cn[which] = pl.channels;
@@ -1250,6 +1273,19 @@ rip_status rip_apply(rip_pipeline* p, const uint8_t* image, int rows, int cols, 
     if (encoding_out) copy_string(pl.encoding_out, encoding_out, 32);
   });
 }
+
+namespace {
+// true for hipHostMalloc'd / hipHostRegister'ed memory (the runtime can DMA from it without a staging copy)
+bool host_pointer_is_pinned(const void* ptr) {
+  hipPointerAttribute_t at;
+  std::memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+    (void)hipGetLastError();  // older runtimes report an ordinary malloc'd pointer as an error
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+}  // namespace
 
 rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step, const char* encoding,
                       uint64_t* ticket) {
@@ -1295,11 +1331,33 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     sl.reserve_host(out_bytes);
     sl.has_deb = (p->tap_mask & RIP_TAP_DEBAYERED) && eb == 1;
     sl.has_col = (p->tap_mask & RIP_TAP_COLOR) && eb == 1;
-    if (sl.has_deb) sl.d_tap_deb.reserve(mid_bytes);
-    if (sl.has_col) sl.d_tap_col.reserve(mid_bytes);
+    if (sl.has_deb) {
+      sl.d_tap_deb.reserve(mid_bytes);
+      RingSlot::reserve_pinned(sl.h_tap[0], sl.h_tap_cap[0], mid_bytes);
+    }
+    if (sl.has_col) {
+      sl.d_tap_col.reserve(mid_bytes);
+      RingSlot::reserve_pinned(sl.h_tap[1], sl.h_tap_cap[1], mid_bytes);
+    }
     // upload (its own stream: it overlaps the kernels of the frame before) -> kernels on the handle's stream, in submission
     // order -> download into the slot's pinned buffer (its own stream: it overlaps the kernels of the frame after)
-    HIP_CHECK(hipMemcpy2DAsync(sl.d_in.ptr, in_pitch, image, step, (size_t)cols * channels * eb, (size_t)rows, hipMemcpyHostToDevice, p->ul_stream));
+    // A frame in pinned memory (rip_host_alloc, hipHostMalloc, hipHostRegister) is DMA'd from where it lies and must stay
+    // untouched until its ticket is collected.  Anything else is copied into the slot's pinned staging buffer first, so the
+    // caller's buffer is free again when this call returns whatever the runtime does with an asynchronous 2-D copy from
+    // pageable memory (above its staging threshold it pins the pages in place and copies after the call has returned).
+    const size_t row_bytes = (size_t)cols * channels * eb;
+    if (host_pointer_is_pinned(image)) {
+      HIP_CHECK(hipMemcpy2DAsync(sl.d_in.ptr, in_pitch, image, step, row_bytes, (size_t)rows, hipMemcpyHostToDevice, p->ul_stream));
+    } else {
+      sl.reserve_host_in(in_bytes);
+      uint8_t* stage = static_cast<uint8_t*>(sl.h_in);
+      if (step == in_pitch) {
+        std::memcpy(stage, image, in_pitch * (size_t)(rows - 1) + row_bytes);
+      } else {
+        for (int r = 0; r < rows; r++) std::memcpy(stage + (size_t)r * in_pitch, image + (size_t)r * step, row_bytes);
+      }
+      HIP_CHECK(hipMemcpyAsync(sl.d_in.ptr, stage, in_bytes, hipMemcpyHostToDevice, p->ul_stream));
+    }
     HIP_CHECK(hipEventRecord(sl.ev_up, p->ul_stream));
     HIP_CHECK(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
     run_batch(p, pl, sl.d_in.as<uint8_t>(), in_pitch, in_bytes, 1, rows, cols, sl.d_out.as<uint8_t>(), 0, 0,
@@ -1307,6 +1365,11 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     HIP_CHECK(hipEventRecord(sl.ev_kernels, p->stream));
     HIP_CHECK(hipStreamWaitEvent(p->dl_stream, sl.ev_kernels, 0));
     HIP_CHECK(hipMemcpyAsync(sl.h_out, sl.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, p->dl_stream));
+    // the taps the mask keeps travel with the result: a per-frame caller that publishes them (raw_image_pipeline_ros.cpp:
+    // 245-287: up to three images per callback) gets them from pinned host memory instead of one synchronous device read
+    // each (rip_get_image / rip_get_image_view after rip_collect)
+    if (sl.has_deb) HIP_CHECK(hipMemcpyAsync(sl.h_tap[0], sl.d_tap_deb.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
+    if (sl.has_col) HIP_CHECK(hipMemcpyAsync(sl.h_tap[1], sl.d_tap_col.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
     HIP_CHECK(hipEventRecord(sl.ev_done, p->dl_stream));
     sl.pl = pl;
     sl.ticket = p->next_ticket++;
@@ -1334,16 +1397,17 @@ rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t ou
     sl->busy = false;
     sl->held = true;
     const bool eb1 = pl.elem_bytes == 1;
-    auto remember = [&](int which, DevBuf* buf, int r, int c, bool on) {
+    auto remember = [&](int which, DevBuf* buf, const void* host, int r, int c, bool on) {
       p->last_valid[which] = on;
       p->last_buf[which] = buf;
+      p->last_host[which] = host;
       p->last_rows[which] = r;
       p->last_cols[which] = c;
       p->last_cn[which] = pl.channels;
     };
-    remember(RIP_IMAGE_DEBAYERED, &sl->d_tap_deb, pl.mid_rows, pl.mid_cols, sl->has_deb);
-    remember(RIP_IMAGE_COLOR, &sl->d_tap_col, pl.mid_rows, pl.mid_cols, sl->has_col);
-    remember(RIP_IMAGE_PROCESSED, &sl->d_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0 && eb1);
+    remember(RIP_IMAGE_DEBAYERED, &sl->d_tap_deb, sl->h_tap[0], pl.mid_rows, pl.mid_cols, sl->has_deb);
+    remember(RIP_IMAGE_COLOR, &sl->d_tap_col, sl->h_tap[1], pl.mid_rows, pl.mid_cols, sl->has_col);
+    remember(RIP_IMAGE_PROCESSED, &sl->d_out, sl->h_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0 && eb1);
     if (out_rows) *out_rows = pl.out_rows;
     if (out_cols) *out_cols = pl.out_cols;
     if (out_channels) *out_channels = pl.channels;
@@ -1401,9 +1465,27 @@ rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_ca
     if (!out) return;  // size query
     if (out_capacity < bytes) throw CapacityError("image buffer too small");
     need_device(p);
+    if (p->last_host[which]) {  // a frame that came through rip_collect: the image is in pinned host memory already
+      std::memcpy(out, p->last_host[which], bytes);
+      return;
+    }
     DeviceGuard device_guard(p->device);
     HIP_CHECK(hipMemcpyAsync(out, p->last_buf[which]->ptr, bytes, hipMemcpyDeviceToHost, p->stream));
     HIP_CHECK(hipStreamSynchronize(p->stream));
+  });
+}
+
+rip_status rip_get_image_view(rip_pipeline* p, int which, const uint8_t** view, int* rows, int* cols, int* channels) {
+  return guarded(p, [&] {
+    need(p);
+    if (!view) throw InvalidArgument("null view");
+    if (which < 0 || which > 3) throw InvalidArgument("unknown image id");
+    *view = nullptr;
+    const bool have = which != RIP_IMAGE_RECT_MASK && p->last_valid[which];
+    if (rows) *rows = have ? p->last_rows[which] : 0;
+    if (cols) *cols = have ? p->last_cols[which] : 0;
+    if (channels) *channels = have ? p->last_cn[which] : 0;
+    if (have) *view = static_cast<const uint8_t*>(p->last_host[which]);
   });
 }
 

@@ -117,8 +117,13 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
   __syncthreads();
   // With the fused finalisation the atomics return their old value: the thread then waits for it, i.e. until the update has
   // been performed at the device's coherence point (agent-scope atomics execute beyond the per-XCD L2s), before the
-  // workgroup barrier below lets thread 0 draw the ticket.  A release fence instead (__threadfence) writes back the XCD's L2
-  // on gfx950 and made this kernel 13 x slower.
+  // workgroup barrier below lets thread 0 draw the ticket.  A release fence instead (__threadfence, or an acq_rel ticket:
+  // both make hipcc emit the agent-scope L2 write-back) made this kernel 13 x slower on gfx950.
+  // HARDWARE ASSUMPTION, outside the HIP memory model: a returned agent-scope atomic HAS been performed where every other
+  // agent-scope atomic on the same address will see it, and only atomics touch these records (the collector below reads
+  // them with atomicExch, never with plain loads).  The asm below is both the use of the returned value (s_waitcnt vmcnt(0)
+  // before it) and a compiler barrier ("memory": nothing moves across it).  tests/test_determinism_gpu.py re-runs the same
+  // batches at several sizes and shard counts and fails on the first record that does not come back zeroed.
   const bool fused = p.wb_out != nullptr;
   StatShard* const mine = &out->shard[blockIdx.x % kStatShards];
   if (threadIdx.x < 5) {
@@ -127,7 +132,7 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
     if (t) {
       if (fused) {
         const unsigned long long old = atomicAdd(&mine->sum[threadIdx.x], t);
-        asm volatile("" ::"v"(old));
+        asm volatile("" ::"v"(old) : "memory");
       } else {
         atomicAdd(&mine->sum[threadIdx.x], t);
       }
@@ -138,7 +143,7 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
     if (t) {
       if (fused) {
         const unsigned old = atomicMax(&mine->mx[threadIdx.x - 5], t);
-        asm volatile("" ::"v"(old));
+        asm volatile("" ::"v"(old) : "memory");
       } else {
         atomicMax(&mine->mx[threadIdx.x - 5], t);
       }

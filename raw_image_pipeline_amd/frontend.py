@@ -129,6 +129,20 @@ class CameraStream:
         return True, "White balance resetted"
 
     # ---- the image callback (:219-288) -------------------------------------------------------------------
+    def _sync_taps(self):
+        """Keeps only the taps the node publishes (:245-287): the debayered image for colour inputs with the debayer on, the
+        pre-undistortion colour image when undistortion is on, the final image always.  (The reference clones all three per
+        frame whatever is published; here a tap that nobody reads costs device writes and, on the pipelined path, a download.)"""
+        from .pipeline import TAP_COLOR, TAP_DEBAYERED, TAP_PROCESSED
+        mask = TAP_PROCESSED
+        if self.input_type == "color" and self.pipe.is_debayer_enabled():
+            mask |= TAP_DEBAYERED
+        if self.pipe.is_undistortion_enabled():
+            mask |= TAP_COLOR
+        if mask != getattr(self, "_tap_mask", None):
+            self.pipe.set_taps(mask)
+            self._tap_mask = mask
+
     def on_image(self, image, encoding, stamp=0.0, frame_id="camera"):
         """Processes one frame and returns the messages the node would publish, in publishing order:
         a list of dicts {topic, image, encoding, camera_info | None}."""
@@ -137,35 +151,50 @@ class CameraStream:
             return []  # ROS_WARN("image empty")
         if self.transport != "raw":
             encoding = "bgr8"  # cv_bridge::toCvCopy(image_msg, "bgr8") for compressed transports
+        self._sync_taps()
         processed = self.pipe.apply(img.copy(), encoding)
         return self._messages(processed, self.pipe.last_encoding, stamp, frame_id)
 
-    def on_image_pipelined(self, image, encoding, stamp=0.0, frame_id="camera"):
+    def submit(self, image, encoding, stamp=0.0, frame_id="camera"):
+        """First half of the callback: enqueues upload, kernels and the download of the result AND of the taps the node
+        publishes (rip_submit) and returns at once.  The frame is read before the call returns.  False for an empty image."""
+        img = np.ascontiguousarray(image)
+        if img.size == 0:
+            return False
+        if self.transport != "raw":
+            encoding = "bgr8"
+        self._sync_taps()
+        ticket = self.pipe.submit(img, encoding)
+        self._inflight = getattr(self, "_inflight", [])
+        self._inflight.append((ticket, stamp, frame_id))
+        return True
+
+    def collect(self, copy=True):
+        """Second half: waits for the OLDEST frame in flight and returns its messages ([] when nothing is in flight).  With
+        ``copy=False`` the images are read-only views of the handle's pinned buffers -- what a publisher that serialises the
+        message at once wants -- valid until the next collect() of this camera."""
+        inflight = getattr(self, "_inflight", [])
+        if not inflight:
+            return []
+        ticket, stamp, frame_id = inflight.pop(0)
+        processed = self.pipe.collect(ticket, copy=copy)
+        return self._messages(processed, self.pipe.last_encoding, stamp, frame_id, copy=copy)
+
+    def on_image_pipelined(self, image, encoding, stamp=0.0, frame_id="camera", copy=True):
         """The same callback with one frame kept in flight (rip_submit / rip_collect): uploads, kernels and downloads of
         neighbouring frames overlap, and the call returns the messages of the PREVIOUS frame (an empty list for the first
         one; flush() delivers the last).  Frames are processed in arrival order, so the white-balance filter sees the
         same sequence as with on_image()."""
-        img = np.ascontiguousarray(image)
-        if img.size == 0:
+        had = len(getattr(self, "_inflight", []))
+        if not self.submit(image, encoding, stamp, frame_id):
             return []
-        if self.transport != "raw":
-            encoding = "bgr8"
-        ticket = self.pipe.submit(img, encoding)
-        out = self.flush()
-        self._pending = (ticket, stamp, frame_id)
-        return out
+        return self.collect(copy=copy) if had else []
 
-    def flush(self):
+    def flush(self, copy=True):
         """Messages of the frame still in flight, if any."""
-        pending = getattr(self, "_pending", None)
-        if pending is None:
-            return []
-        self._pending = None
-        ticket, stamp, frame_id = pending
-        processed = self.pipe.collect(ticket)
-        return self._messages(processed, self.pipe.last_encoding, stamp, frame_id)
+        return self.collect(copy=copy)
 
-    def _messages(self, processed, enc, stamp, frame_id):
+    def _messages(self, processed, enc, stamp, frame_id, copy=True):
         out = []
         pipe = self.pipe
         if pipe.is_undistortion_enabled():
@@ -177,9 +206,10 @@ class CameraStream:
                 pipe.get_dist_distortion_coefficients(), pipe.get_dist_camera_matrix(), pipe.get_dist_rectification_matrix(),
                 pipe.get_dist_projection_matrix())
         if self.input_type == "color" and pipe.is_debayer_enabled():
-            self._publish(out, pipe.get_dist_debayered_image(), enc, stamp, frame_id, "debayered/image", "debayered/slow", *dist,
+            self._publish(out, pipe.get_dist_debayered_image(copy=copy), enc, stamp, frame_id, "debayered/image", "debayered/slow", *dist,
                           "_skipped")
-        color = pipe.get_dist_color_image() if pipe.is_undistortion_enabled() else pipe.get_processed_image()
+        # getProcessedImage() (:283) is the image apply() has just returned: no second read of it
+        color = pipe.get_dist_color_image(copy=copy) if pipe.is_undistortion_enabled() else processed
         self._publish(out, color, enc, stamp, frame_id, self.input_type + "/image", self.input_type + "/image/slow", *dist, "_skipped")
         return out
 
@@ -233,15 +263,29 @@ class CameraRig:
             self.devices.append(dev)
             self.hip_streams.append(s)
 
-    def on_images(self, images, encodings, stamp=0.0, parallel=True):
-        """One frame per camera (the synchronised trigger of a multi-camera rig).  With `parallel` every camera's
-        host -> device copy, kernels and device -> host copy run on its own thread and HIP stream (the C call
-        releases the GIL), so one camera's read-back overlaps the next one's upload and kernels: the host path is
-        PCIe-bound and the link is full duplex."""
+    def on_images(self, images, encodings, stamp=0.0, parallel=True, mode=None, copy=True):
+        """One frame per camera (the synchronised trigger of a multi-camera rig).  Modes:
+
+        * ``"pipelined"`` (default): ONE thread submits every camera's frame (rip_submit: upload, kernels and the downloads
+          of result + published taps are only enqueued, each camera on its own handle and streams) and then collects them
+          in camera order, so camera c's downloads overlap camera c + 1's upload and kernels -- the host path is PCIe-bound
+           and the link is full duplex.  No thread, no GIL hand-over, no per-call pool latency.
+        * ``"threaded"``: one thread per camera around the synchronous callback (the shape of one ROS node per camera);
+          kept as an option -- on a many-core host its wake-ups cost more than the overlap gives at small frames.
+        * ``"sequential"`` (or ``parallel=False``): camera after camera, synchronously.
+
+        ``copy=False`` (pipelined only): images are read-only views of pinned memory, valid until the next trigger."""
+        if mode is None:
+            mode = "pipelined" if parallel else "sequential"
         jobs = list(enumerate(zip(self.streams, images, encodings)))
         run = lambda job: job[1][0].on_image(job[1][1], job[1][2], stamp=stamp, frame_id="cam%d" % job[0])
-        if not parallel or len(jobs) < 2:
+        if mode == "sequential" or len(jobs) < 2:
             return [run(j) for j in jobs]
+        if mode == "pipelined":
+            sent = [cam.submit(img, enc, stamp=stamp, frame_id="cam%d" % c) for c, (cam, img, enc) in jobs]
+            return [cam.collect(copy=copy) if ok else [] for ok, (c, (cam, img, enc)) in zip(sent, jobs)]
+        if mode != "threaded":
+            raise ValueError("mode must be 'pipelined', 'threaded' or 'sequential'")
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=len(self.streams), thread_name_prefix="rip-camera")

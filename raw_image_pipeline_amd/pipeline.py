@@ -65,6 +65,25 @@ def _as_doubles(values, n=None):
     return arr, len(values)
 
 
+def host_alloc(shape, dtype=np.uint8):
+    """A numpy array over page-locked host memory (rip_host_alloc): frames handed to ``submit`` from it are uploaded
+    asynchronously without the staging copy a pageable frame gets -- and must stay untouched until their ``collect``.
+    The memory is released with the array."""
+    import weakref
+    lib = load_library()
+    lib.rip_host_alloc.restype = C.c_void_p
+    lib.rip_host_alloc.argtypes = [C.c_size_t]
+    lib.rip_host_free.restype = None
+    lib.rip_host_free.argtypes = [C.c_void_p]
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = lib.rip_host_alloc(max(n, 1))
+    if not ptr:
+        raise MemoryError("rip_host_alloc(%d) failed" % n)
+    raw = (C.c_uint8 * max(n, 1)).from_address(ptr)
+    weakref.finalize(raw, lib.rip_host_free, C.c_void_p(ptr))  # the ctypes object is the base of every view below
+    return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class RawImagePipeline:
     """Same surface as ``py_raw_image_pipeline.RawImagePipeline``.
 
@@ -181,7 +200,9 @@ class RawImagePipeline:
 
     def collect(self, ticket, copy=True):
         """Waits for the frame of ``ticket`` and returns its image (rip_collect).  ``copy=False`` returns a read-only view of
-        the handle's pinned result buffer instead: valid until ``ring depth`` further frames have been submitted."""
+        the handle's pinned result buffer instead.  As rip.h says of rip_collect's view: it is valid until the NEXT ``collect``
+        on this pipeline -- or until a ``submit`` finds every other slot in flight and takes this one (keep at most
+        ``ring depth - 1`` frames in flight to hold on to a view while submitting); copy what must live longer."""
         r, c, k = C.c_int(), C.c_int(), C.c_int()
         enc = C.create_string_buffer(32)
         view = C.c_void_p()
@@ -255,8 +276,20 @@ class RawImagePipeline:
     def set_taps(self, mask):
         self._call("rip_set_taps", int(mask))
 
-    def _get_image(self, which):
+    def _get_image(self, which, copy=True):
+        """``copy=False``: for a frame that came through ``collect`` a read-only view of the handle's pinned host memory
+        (rip_get_image_view; same lifetime as ``collect(copy=False)``); frames of ``process`` only exist on the device and are
+        copied as before."""
         r, c, k = C.c_int(), C.c_int(), C.c_int()
+        if not copy:
+            view = C.c_void_p()
+            self._call("rip_get_image_view", which, C.byref(view), C.byref(r), C.byref(c), C.byref(k))
+            if view.value:
+                n = r.value * c.value * k.value
+                arr = np.frombuffer((C.c_uint8 * n).from_address(view.value), np.uint8)
+                arr = arr.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
+                arr.flags.writeable = False
+                return arr
         self._call("rip_get_image", which, None, C.c_size_t(0), C.byref(r), C.byref(c), C.byref(k))
         if r.value == 0 or c.value == 0:
             return np.empty((0, 0), np.uint8)
@@ -265,17 +298,17 @@ class RawImagePipeline:
                    C.byref(k))
         return out.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
 
-    def get_dist_debayered_image(self):
-        return self._get_image(IMAGE_DEBAYERED)
+    def get_dist_debayered_image(self, copy=True):
+        return self._get_image(IMAGE_DEBAYERED, copy)
 
-    def get_dist_color_image(self):
-        return self._get_image(IMAGE_COLOR)
+    def get_dist_color_image(self, copy=True):
+        return self._get_image(IMAGE_COLOR, copy)
 
     def get_rect_mask(self):
         return self._get_image(IMAGE_RECT_MASK)
 
-    def get_processed_image(self):
-        return self._get_image(IMAGE_PROCESSED)
+    def get_processed_image(self, copy=True):
+        return self._get_image(IMAGE_PROCESSED, copy)
 
     # ---- loaders ---------------------------------------------------------------------------------
     def load_params(self, path):

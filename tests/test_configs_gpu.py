@@ -128,3 +128,39 @@ def test_bench_two_rank_rehearsal_prints_one_json_line():
     assert j["config"]["frames_per_step_per_gpu"] == 8
     assert abs(j["value"] - 2 * 8 * 2 / (j["ms_per_step"] * 2 * 1e-3)) / j["value"] < 1e-3  # whole-job frames / max-over-ranks time
     assert j["scatter"]["ranks"] == 2 and j["scatter"]["frames_per_destination"] > 0 and j["scatter"]["GBps_per_destination"] > 0
+
+
+def test_bench_gpus_2_called_plainly_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no RANK in the environment re-runs itself under
+    torch.distributed.run (gloo rehearsal: both ranks share device 0) and the line says what ran: n_gpus = 2, two ranks counted
+    by a collective over the communicator, two per-rank rates."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(RIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2
+    assert j["communicator"]["ranks_counted"] == 2 and j["communicator"]["world_size"] == 2
+    assert len(j["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in j["per_rank_frames_per_s"])
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`--gpus N` over RCCL on a node with fewer than N devices exits non-zero and prints no line -- never a single-GPU
+    number under an N-GPU label."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RIP_BENCH_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--batch", "2",
+           "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout
+    assert "--gpus %d" % n in r.stderr
+    # and a launcher environment that disagrees with --gpus is refused as well (here: WORLD_SIZE=1 under --gpus 2, gloo)
+    env2 = dict(env, RIP_BENCH_BACKEND="gloo", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run(cmd[:3] + ["2"] + cmd[4:], env=env2, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -78,8 +78,8 @@ def build_rig_example(tmp_path, branch):
 
 @pytest.mark.parametrize("branch", sorted(BRANCHES))
 def test_camera_rig_example_compiles_and_refuses_to_run_without_a_device(tmp_path, rip_lib, branch):
-    """examples/camera_rig.cpp (include/raw_image_pipeline/camera_rig.hpp: one handle and one worker thread per camera,
-    camera c on devices[c % n]) builds as C++14 on both Mat branches; without a HIP device it fails loudly."""
+    """examples/camera_rig.cpp (include/raw_image_pipeline/camera_rig.hpp: one handle per camera, camera c on devices[c % n],
+    cameras overlapped with submit / collect from one thread, worker threads as an option) builds as C++14 on both Mat branches; without a HIP device it fails loudly."""
     import torch
     exe = build_rig_example(tmp_path, branch)
     if torch.cuda.is_available():
@@ -90,8 +90,9 @@ def test_camera_rig_example_compiles_and_refuses_to_run_without_a_device(tmp_pat
 
 @pytest.mark.gpu
 def test_camera_rig_example_two_cameras_on_device_0_match_oracle(tmp_path, rip_lib, oracle):
-    """Two cameras with different parameters (gamma, white-balance method), driven concurrently from their own threads on
-    device 0 through the C++ rig: the last frame of each equals the oracle's result for that camera's configuration."""
+    """Two cameras with different parameters (gamma, white-balance method) on device 0 through the C++ rig, overlapped with
+    submit / collect from one thread and once more from one worker thread each (the example compares the two itself): the
+    last frame of each camera equals the oracle's result for that camera's configuration."""
     from helpers import cfg, oracle_run
     exe = build_rig_example(tmp_path, "stand-in")
     w, h, n_frames = 96, 64, 5
@@ -110,3 +111,26 @@ def test_camera_rig_example_two_cameras_on_device_0_match_oracle(tmp_path, rip_l
         ref, _ = oracle_run(oracle, conf, frame, "bayer_rggb8")
         got = np.fromfile(prefix + "%d.bin" % c, np.uint8).reshape(h, w, 3)
         assert np.array_equal(got, ref), "camera %d" % c
+
+
+REF_BINDING = "/root/reference/raw_image_pipeline_python/src/raw_image_pipeline_python.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BINDING), reason="reference tree not mounted (GPU box)")
+def test_reference_pybind_module_type_checks_unchanged_against_the_facade(tmp_path):
+    """the reference's own pybind11 module source (raw_image_pipeline_python.cpp:14-73: 51 `.def`
+    lines taking the address of a RawImagePipeline method each) compiles UNCHANGED against this repository's
+    <raw_image_pipeline/raw_image_pipeline.hpp>.  The file is read in place (nothing is copied into the repository, and the
+    test does not exist on the GPU box); `-fsyntax-only` does the full C++14 front end -- overload resolution of every
+    `&RawImagePipeline::method`, pybind11's signature deduction -- without needing Python or OpenCV to link against.  OpenCV and
+    cvnp are absent from the image: <opencv2/core.hpp> is the test-only stand-in, <cvnp/cvnp.h> (the cv::Mat <-> numpy caster of
+    the reference's binding, out of scope by SURVEY 8) an empty header made on the spot."""
+    import sysconfig
+    import pybind11
+    os.makedirs(str(tmp_path / "cvnp"))
+    with open(str(tmp_path / "cvnp" / "cvnp.h"), "w") as f:
+        f.write("#pragma once\n")
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", str(tmp_path), "-I", os.path.join(ROOT, "tests", "cpp", "fake_opencv"),
+           "-I", os.path.join(ROOT, "include"), "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"], REF_BINDING]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]

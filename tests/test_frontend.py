@@ -115,24 +115,44 @@ def test_compressed_transport_forces_bgr8(rip_lib):
 
 
 @pytest.mark.gpu
-def test_camera_rig_runs_cameras_in_parallel_with_identical_results(rip_lib, capsys):
-    """Four cameras of a rig on one GPU: the threaded host path (one thread + HIP stream per camera) publishes exactly
-    what the sequential one does; the throughput of both is printed for the record."""
+@pytest.mark.parametrize("w,h,full", [(640, 480, False), (2448, 2048, True)])
+def test_camera_rig_overlaps_cameras_with_identical_results(rip_lib, capsys, tmp_path, w, h, full):
+    """Four cameras of a rig on one GPU (raw_image_pipeline_ros.cpp:219-288 is the callback, one
+    node per camera in raw_image_pipeline_node.launch:85).  Every mode publishes exactly what the sequential one does.  The
+    default mode overlaps the cameras with rip_submit / rip_collect from ONE thread and must not lose to the sequential
+    callback at 640x480 (>= 0.95 x) and must win at 2448x2048 with all three published images per frame (>= 1.3 x, images
+    handed over as views of pinned memory: the publisher serialises them at once); the threaded mode is an option and is only
+    reported."""
     import time
     from raw_image_pipeline_amd.frontend import CameraRig
-    w, h, ncam = 640, 480, 4
-    params = [{"output_prefix": "/cam%d" % c, "flip/enabled": True, "flip/angle": 180, "gamma_correction/enabled": True,
-               "gamma_correction/k": 0.8 + 0.05 * c, "white_balance/enabled": True, "white_balance/method": "gray_world"} for c in range(ncam)]
+    ncam = 4
+    params = []
+    calib = str(tmp_path / "calib.yaml")
+    with open(calib, "w") as f:
+        f.write(synth.calibration_yaml(synth.camera_model(w, h)))
+    for c in range(ncam):
+        prm = {"output_prefix": "/cam%d" % c, "flip/enabled": True, "flip/angle": 180, "gamma_correction/enabled": True,
+               "gamma_correction/k": 0.8 + 0.05 * c, "white_balance/enabled": True, "white_balance/method": "gray_world"}
+        if full:
+            prm.update({"undistortion/enabled": True, "undistortion/calibration_file": calib})
+        params.append(prm)
     rig = CameraRig(params, n_devices=1)
     frames = [synth.gen_frame(w, h, "bayer_rggb8", seed=70 + c, kind="scene") for c in range(ncam)]
     enc = ["bayer_rggb8"] * ncam
-    seq = rig.on_images(frames, enc, stamp=1.0, parallel=False)
+    seq = rig.on_images(frames, enc, stamp=1.0, mode="sequential")
+    if full:
+        assert [m["topic"] for m in seq[0] if not m["topic"].endswith("slow")] == ["/cam0/color_rect/image", "/cam0/debayered/image", "/cam0/color/image"]
     rates = {}
-    for mode in (False, True):
-        t0 = time.perf_counter()
-        for _ in range(5):
-            got = rig.on_images(frames, enc, stamp=1.0, parallel=mode)
-        rates[mode] = 5 * ncam / (time.perf_counter() - t0)
+    reps = 3 if full else 8
+    for mode, copy in (("sequential", True), ("pipelined", True), ("pipelined", False), ("threaded", True)):
+        best = None
+        for _ in range(3):  # best of three passes: the boxes are shared and a timing assertion must not see a neighbour's burst
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                got = rig.on_images(frames, enc, stamp=1.0, mode=mode, copy=copy)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        rates[(mode, copy)] = reps * ncam / best
         assert len(got) == ncam
         for c in range(ncam):
             assert [m["topic"] for m in got[c] if not m["topic"].endswith("slow")] == \
@@ -141,6 +161,11 @@ def test_camera_rig_runs_cameras_in_parallel_with_identical_results(rip_lib, cap
             b = {m["topic"]: m["image"] for m in seq[c]}
             for t in a:
                 if t in b:
-                    assert np.array_equal(a[t], b[t]), (mode, c, t)
+                    assert np.array_equal(a[t], b[t]), (mode, copy, c, t)
     with capsys.disabled():
-        print("\ncamera rig host path, %d cameras %dx%d: sequential %.0f frames/s, threaded %.0f frames/s" % (ncam, w, h, rates[False], rates[True]))
+        print("\ncamera rig host path, %d cameras %dx%d, frames/s: sequential %.0f, pipelined %.0f (views: %.0f), threaded %.0f"
+              % (ncam, w, h, rates[("sequential", True)], rates[("pipelined", True)], rates[("pipelined", False)], rates[("threaded", True)]))
+    if full:
+        assert rates[("pipelined", False)] >= 1.3 * rates[("sequential", True)], rates
+    else:
+        assert rates[("pipelined", True)] >= 0.95 * rates[("sequential", True)], rates

@@ -723,3 +723,54 @@ def test_submit_collect_stream_of_32_frames_ccc_temporal(rip_lib, oracle, depth)
     for i in range(n):
         assert_images_equal(got[i], refs[i][0], "submit/collect frame %d (depth %d)" % (i, depth))
     assert pipe.last_encoding == "bgr8"
+
+
+@pytest.mark.gpu
+def test_submit_reads_a_pageable_5_MB_frame_before_it_returns(rip_lib):
+    """rip.h promises that a pageable frame is read before rip_submit returns.  A 2448x2048 frame (5 MB: far
+    above any staging threshold of the runtime's asynchronous 2-D copy) is overwritten the moment submit() returns, three
+    frames in flight from ONE reused buffer; every collected frame -- and the taps that travel with it -- must equal the
+    synchronous process() of the original frame.  A frame in pinned memory (host_alloc) takes the copy-free branch."""
+    from raw_image_pipeline_amd import RawImagePipeline
+    from raw_image_pipeline_amd.pipeline import host_alloc
+    w, h = 2448, 2048
+    pipe = RawImagePipeline(False, "", "", "", device=0)
+    c = cfg(flip=True, flip_angle=180, wb=True, wb_method="gray_world", wb_bright=0.8, cc=True, gamma=True, gamma_k=0.8, vig=True,
+            undistort=True, cam=synth.camera_model(w, h))
+    configure(pipe, c)
+    frames = [synth.gen_frame(w, h, "bayer_rggb8", seed=900 + i, kind="scene", tint=(0.6 + 0.1 * i, 1.0, 0.7)) for i in range(3)]
+    want, want_deb, want_col = [], [], []
+    for f in frames:
+        want.append(pipe.process(f, "bayer_rggb8"))
+        want_deb.append(pipe.get_dist_debayered_image())
+        want_col.append(pipe.get_dist_color_image())
+    assert not np.array_equal(want[0], want[1])
+    buf = np.empty((h, w), np.uint8)
+    tickets = []
+    for i, f in enumerate(frames):
+        buf[...] = f
+        tickets.append(pipe.submit(buf, "bayer_rggb8"))
+        buf[...] = 0xA5 ^ i  # the caller's buffer is the caller's again
+    for i, t in enumerate(tickets):
+        got = pipe.collect(t, copy=False)
+        assert_images_equal(got, want[i], "pageable submit, frame %d" % i)
+        deb = pipe.get_dist_debayered_image(copy=False)
+        col = pipe.get_dist_color_image(copy=False)
+        assert not deb.flags.writeable and not col.flags.writeable  # views of the slot's pinned buffers
+        assert_images_equal(deb, want_deb[i], "debayered tap of frame %d" % i)
+        assert_images_equal(col, want_col[i], "colour tap of frame %d" % i)
+        assert_images_equal(pipe.get_processed_image(), want[i], "processed tap (copy) of frame %d" % i)
+    # a pitched pageable frame (row stride > width) goes through the row-by-row staging copy
+    wide = np.zeros((h, w + 64), np.uint8)
+    wide[:, :w] = frames[1]
+    t = pipe.submit(wide[:, :w], "bayer_rggb8")
+    wide[...] = 7
+    assert_images_equal(pipe.collect(t), want[1], "pitched pageable submit")
+    # pinned memory: uploaded from where it lies
+    pinned = host_alloc((h, w))
+    pinned[...] = frames[2]
+    t = pipe.submit(pinned, "bayer_rggb8")
+    assert_images_equal(pipe.collect(t), want[2], "pinned submit")
+    # frames of the synchronous path have no host view: the getter falls back to the device read
+    pipe.process(frames[0], "bayer_rggb8")
+    assert_images_equal(pipe.get_dist_color_image(copy=False), want_col[0], "tap of a process() frame through the view getter")
