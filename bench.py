@@ -71,7 +71,16 @@ def make_frames(width, height, pattern, batch, rank, distinct=4):
     """`batch` synthetic Bayer frames: `distinct` seeded scenes (seed = 1000*camera + frame) plus
     even-offset rolls of them (keeps the Bayer phase, changes every pixel's neighbourhood)."""
     from raw_image_pipeline_amd import synth
-    base = [synth.gen_frame(width, height, pattern, seed=1000 * rank + i, kind="scene") for i in range(min(distinct, batch))]
+    # RIP_BENCH_FRAMES (development only; the driver's line is always "scene"): "flat" = one colour per channel, every lane of a
+    # wave looks up the same table entries (no LDS bank conflicts: what the fused chain costs in instructions alone);
+    # "uniform" = iid bytes (the worst case for the table lookups)
+    kind = os.environ.get("RIP_BENCH_FRAMES", "scene")
+    if kind == "flat":
+        bgr = np.empty((height, width, 3), np.uint8)
+        bgr[...] = (66, 120, 84)
+        base = [synth.mosaic(bgr, pattern)]
+    else:
+        base = [synth.gen_frame(width, height, pattern, seed=1000 * rank + i, kind=kind) for i in range(min(distinct, batch))]
     frames = []
     for i in range(batch):
         f = base[i % len(base)]
@@ -232,17 +241,30 @@ def live_pmc_traffic(args, kernel_class):
                     if pat in row["Kernel_Name"] and row["Counter_Name"] in counter.split():
                         per.setdefault((row["Kernel_Name"], row["Counter_Name"]), []).append(float(row["Counter_Value"]))
             if factor is None:
-                # issue counters of the dominant kernel (the longest of the class): VALU wave-instructions per SIMD per cycle.
-                # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (tools/collect_pmc_sq.py); 1024 SIMDs; 0.5 = one
-                # wave64 instruction per 2 cycles, the SIMD-32 issue ceiling.
-                gui = {k[0]: med(v) for k, v in per.items() if k[1] == "GRBM_GUI_ACTIVE"}
-                if gui:
-                    kn = max(gui, key=lambda k: gui[k])
-                    insts = med(per.get((kn, "SQ_INSTS_VALU"), []))
-                    if insts and gui[kn]:
-                        cycles = gui[kn] / 8.0
-                        valu = {"kernel": kn.split("(")[0][-60:], "valu_wave_instructions": int(insts), "kernel_cycles": int(cycles),
-                                "valu_instr_per_simd_cycle": round(insts / 1024.0 / cycles, 4)}
+                # issue counters: VALU wave-instructions per SIMD per cycle.  GRBM_GUI_ACTIVE comes back summed over the 8
+                # XCDs (tools/collect_pmc_sq.py); 1024 SIMDs; 0.5 = one wave64 instruction per 2 cycles, the SIMD-32 issue
+                # ceiling.  Collected for EVERY kernel of the run (the counters are not filtered by class): the dominant one
+                # goes into roofline.valu, all of them into roofline.per_kernel.
+                every = {}
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if row["Counter_Name"] in counter.split():
+                            every.setdefault((row["Kernel_Name"], row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+                allk = {}
+                for (kn, cn), v in every.items():
+                    if cn != "GRBM_GUI_ACTIVE" or not med(v):
+                        continue
+                    insts = med(every.get((kn, "SQ_INSTS_VALU"), []))
+                    cls = next((c for c, pt in (("stats", "stats_"), ("chain", "chain_"), ("remap", "remap_"), ("ccc", "ccc_")) if pt in kn), None)
+                    if cls is None or insts is None:
+                        continue
+                    cycles = med(v) / 8.0
+                    rec = {"kernel": kn.split("(")[0][-60:], "valu_wave_instructions": int(insts), "kernel_cycles": int(cycles),
+                           "valu_instr_per_simd_cycle": round(insts / 1024.0 / cycles, 4)}
+                    if cls not in allk or cycles > allk[cls]["kernel_cycles"]:  # the longest kernel of the class
+                        allk[cls] = rec
+                if kernel_class in allk:
+                    valu = dict(allk[kernel_class], all_classes=allk)
                 continue
             if not per:
                 return None, None, "rocprofv3 --pmc %s produced no rows (rc %d)" % (counter, r.returncode)
@@ -290,12 +312,21 @@ def committed_single_gpu_value(workload):
     return best
 
 
-def hbm_probe(torch, nbytes=1 << 30, reps=10):
-    """Streaming copy and read-only rates of this GPU (torch elementwise kernels), GB/s of bytes moved."""
+def hbm_probe(pipe, torch, nbytes=1 << 30, reps=10):
+    """What this box's memory system delivers to plain streaming kernels, GB/s of bytes moved (read + written), best of
+    `reps` launches each: the library's own hand-written kernels (rip_debug_hbm_probe, csrc/rip_probe.hip: 16-byte copy, read,
+    fill, the chain's 1 : 3 expand with ordinary and non-temporal stores, a 12-byte-lane copy) -- and, for continuity with the
+    round-1..3 lines, torch's elementwise copy_ and sum, which run 15-20 % below them."""
+    res = {}
+    for kind in ("copy", "read", "fill", "expand13", "expand13_nt", "copy12"):
+        try:
+            res[kind + "_GBps"] = round(pipe.hbm_probe(kind, nbytes, reps), 1)
+        except Exception as e:  # noqa: BLE001 -- the bench line must come out whatever a probe does
+            res[kind + "_GBps"] = None
+            res.setdefault("errors", []).append("%s: %s" % (kind, str(e)[:120]))
     src = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda").fill_(1)
     dst = torch.empty_like(src)
-    res = {}
-    for name, fn, moved in (("copy_GBps", lambda: dst.copy_(src), 2 * nbytes), ("read_GBps", lambda: src.view(torch.int64).sum(), nbytes)):
+    for name, fn, moved in (("torch_copy_GBps", lambda: dst.copy_(src), 2 * nbytes), ("torch_read_GBps", lambda: src.view(torch.int64).sum(), nbytes)):
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -305,6 +336,7 @@ def hbm_probe(torch, nbytes=1 << 30, reps=10):
         e1.record()
         torch.cuda.synchronize()
         res[name] = round(moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    res["source"] = "rip_debug_hbm_probe (hand-written, best of %d launches over %d MiB); torch_* = torch elementwise kernels, average of %d" % (reps, nbytes >> 20, reps)
     return res
 
 
@@ -520,9 +552,32 @@ def main():
     if world == 1 and not args.no_pmc:
         live, valu_live, why = live_pmc_traffic(args, dom)
         if valu_live is not None:
+            allk = valu_live.pop("all_classes", {})
             v = roofline.setdefault("valu", {"model": None, "peak_instr_per_simd_cycle": 0.5})
             v["measured"] = dict(valu_live, source="this run: rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE, median launch of the dominant kernel")
             v["measured_frac"] = round(valu_live["valu_instr_per_simd_cycle"] / 0.5, 4)
+            # The instruction floor: the time the launch would take if every VALU instruction it
+            # EXECUTES (counted by the hardware, not by a listing) issued at the SIMD's full rate of one wave64 instruction per
+            # 2 cycles with nothing else in the way -- no quarter-rate opcodes, no LDS, no memory.  floor_ms = instructions /
+            # (1024 SIMDs x 0.5) / clock, the clock taken from the same launch (kernel cycles / measured duration).
+            # valu_floor_frac is what `frac` would be at that floor: the ceiling this instruction stream puts on the kernel's
+            # HBM roofline fraction, below 1 whenever the kernel cannot be HBM-bound by construction.
+            per_kernel = {}
+            for cls, rec in allk.items():
+                if cls not in prof or not prof[cls][1] or bytes_per_px(cls, args.batch) <= 0:
+                    continue
+                ms = prof[cls][0] / prof[cls][1]
+                floor_ms = ms * (rec["valu_wave_instructions"] / 512.0) / rec["kernel_cycles"]
+                alg = bytes_per_px(cls, args.batch) * (orows * ocols if cls == "remap" else px) * args.batch
+                per_kernel[cls] = {"avg_launch_ms": round(ms, 4), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "valu_instr_per_simd_cycle": rec["valu_instr_per_simd_cycle"],
+                                   "valu_floor_ms": round(floor_ms, 4),
+                                   "valu_floor_frac": round(min(1.0, alg / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS), 4),
+                                   "clock_GHz": round(rec["kernel_cycles"] / (ms * 1e-3) / 1e9, 3)}
+            roofline["per_kernel"] = per_kernel
+            if dom in per_kernel:
+                roofline["valu_floor_frac"] = per_kernel[dom]["valu_floor_frac"]
+                roofline["valu_floor_ms"] = per_kernel[dom]["valu_floor_ms"]
         if live is not None:
             roofline["traffic"] = live
             roofline["traffic_source"] = ("measured in this run: the same command re-run under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
@@ -532,9 +587,19 @@ def main():
     if world == 1 and not args.no_hbm_probe:
         # what this box's HBM actually delivers to a plain streaming kernel, beside the 8 TB/s spec
         del out
-        probe = hbm_probe(torch)
-        roofline["empirical"] = dict(probe, frac_of_copy=round(achieved / probe["copy_GBps"], 4) if probe["copy_GBps"] else None,
-                                     frac_of_read=round(achieved / probe["read_GBps"], 4) if probe["read_GBps"] else None)
+        probe = hbm_probe(pipe, torch)
+        # the access shape that bounds each class: the chain is a 1 : 3 expand (non-temporal stores when nothing reads the image
+        # again), the remap gathers 3 B and writes 3 B per pixel (12-byte lanes), the statistics pre-pass only reads
+        shape = {"chain": "expand13_nt_GBps" if not pipe.is_undistortion_enabled() else "expand13_GBps", "remap": "copy12_GBps", "stats": "read_GBps"}
+        ceil = probe.get(shape.get(dom, "copy_GBps")) or probe.get("copy_GBps")
+        roofline["empirical"] = dict(probe, shape_of_dominant_kernel=shape.get(dom, "copy_GBps"),
+                                     frac_of_shape=round(achieved / ceil, 4) if ceil else None,
+                                     frac_of_copy=round(achieved / probe["copy_GBps"], 4) if probe.get("copy_GBps") else None,
+                                     frac_of_read=round(achieved / probe["read_GBps"], 4) if probe.get("read_GBps") else None)
+        # every streaming class against its own shape's measured rate, on ACTUAL bytes where the PMC passes have them
+        if roofline.get("kernel_GBps"):
+            roofline["empirical"]["per_kernel_frac_of_shape"] = {
+                k: round(v / probe[shape[k]], 4) for k, v in roofline["kernel_GBps"].items() if k in shape and probe.get(shape[k])}
     result = {
         "metric": baseline_metric(),
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -283,6 +283,20 @@ rip_status rip_debug_write_png(rip_pipeline* p, const char* path, const uint8_t*
  * "remap_ring", "remap_stages", "remap_per_cu", "remap_frames", "remap_tiled", "ccc_lds_hist_min", "overlap_groups";
  * value 0 restores the built-in default where the tunable has one.  Unknown names: RIP_ERR_INVALID_ARGUMENT. */
 rip_status rip_set_tunable(rip_pipeline* p, const char* name, int value);
+/* Streaming microbenchmarks on the handle's device and stream (measurement hook, no reference counterpart): what this box's
+ * memory system delivers to the access shapes the pipeline's kernels are made of -- bench.py reports them as
+ * roofline.empirical beside the 8 TB/s spec figure.  `bytes` = size of the source stream (of the destination for FILL),
+ * rounded down to a multiple of 48; the call allocates its buffers, runs one warm-up launch and `reps` timed ones (HIP events
+ * on the handle's stream) and returns the BEST launch as GB/s (1e9) of bytes moved, read + written. */
+enum {
+  RIP_PROBE_COPY = 0,        /* 16 B per lane in, 16 B out (1 : 1) */
+  RIP_PROBE_READ = 1,        /* 16 B per lane in, one dword per wave out */
+  RIP_PROBE_FILL = 2,        /* 16 B per lane out */
+  RIP_PROBE_EXPAND13 = 3,    /* 4 B per lane in, 12 B out: the fused chain's shape */
+  RIP_PROBE_EXPAND13_NT = 4, /* the same with non-temporal stores (how the chain writes an image nothing reads again) */
+  RIP_PROBE_COPY12 = 5       /* 12 B per lane in and out: the remap's store shape fed by a contiguous read */
+};
+rip_status rip_debug_hbm_probe(rip_pipeline* p, int kind, size_t bytes, int reps, double* gbps);
 const char* rip_version(void);
 
 #ifdef __cplusplus

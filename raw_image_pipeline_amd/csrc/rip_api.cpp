@@ -1848,6 +1848,52 @@ rip_status rip_set_tunable(rip_pipeline* p, const char* name, int value) {
   });
 }
 
+rip_status rip_debug_hbm_probe(rip_pipeline* p, int kind, size_t bytes, int reps, double* gbps) {
+  return guarded(p, [&] {
+    need_device(p);
+    if (!gbps) throw InvalidArgument("null result pointer");
+    if (kind < RIP_PROBE_COPY || kind > RIP_PROBE_COPY12) throw InvalidArgument("unknown probe kind");
+    bytes = bytes / 48 * 48;
+    if (bytes < 48 || reps < 1) throw InvalidArgument("rip_debug_hbm_probe: at least 48 bytes and one repetition");
+    DeviceGuard device_guard(p->device);
+    DevBuf src, dst;
+    const bool expands = kind == RIP_PROBE_EXPAND13 || kind == RIP_PROBE_EXPAND13_NT;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    try {
+      if (kind != RIP_PROBE_FILL) {
+        src.reserve(bytes);
+        HIP_CHECK(hipMemsetAsync(src.ptr, 0x3c, bytes, p->stream));
+      }
+      dst.reserve(expands ? 3 * bytes : bytes);
+      HIP_CHECK(hipEventCreate(&e0));
+      HIP_CHECK(hipEventCreate(&e1));
+      size_t moved = rip::launch_hbm_probe(kind, src.ptr, dst.ptr, bytes, p->stream);  // warm-up: page tables, caches, clocks
+      HIP_CHECK(hipGetLastError());
+      float best = 0.f;
+      for (int r = 0; r < reps; r++) {
+        HIP_CHECK(hipEventRecord(e0, p->stream));
+        moved = rip::launch_hbm_probe(kind, src.ptr, dst.ptr, bytes, p->stream);
+        HIP_CHECK(hipEventRecord(e1, p->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms > 0.f && (best == 0.f || ms < best)) best = ms;
+      }
+      *gbps = best > 0.f ? (double)moved / (best * 1e-3) / 1e9 : 0.0;
+    } catch (...) {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      src.release();
+      dst.release();
+      throw;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    src.release();
+    dst.release();
+  });
+}
+
 int rip_get_table(rip_pipeline* p, int which, int32_t* out, int cap) {
   if (!p || !out) return -1;
   const rip::ColorTables& c = rip::color_tables();

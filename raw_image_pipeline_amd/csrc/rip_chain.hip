@@ -280,12 +280,6 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
 #pragma unroll
         for (int c = 0; c < 4; c++) asm volatile("" : "+v"(w.pca[c]));
       }
-      if constexpr (WB == WB_Q8) {
-        // once per frame instead of once per row: hipcc otherwise masks the gains to 24 bits in front of every second
-        // v_mul_u32_u24 (the instruction ignores the upper bits anyway)
-#pragma unroll
-        for (int c = 0; c < 3; c++) w.q8[c] &= 0xffffff;
-      }
       Window win;
       load_window(src, wo, win);
       Planar rowpx[2];

@@ -587,6 +587,11 @@ __device__ __forceinline__ void lds_u8_hi(uint32_t& d, unsigned addr) { asm vola
 struct Pack3 {
   uint32_t a, b, c;
 };
+__device__ __forceinline__ uint32_t lshl8_or(uint32_t a, uint32_t b) {  // (a << 8) | b
+  uint32_t d;
+  asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ Pack3 invg_pack4(const unsigned (&addr)[4][3]) {
   const unsigned* f = &addr[0][0];  // output byte j comes from f[j]
   uint32_t v[12];
@@ -600,10 +605,12 @@ __device__ __forceinline__ Pack3 invg_pack4(const unsigned (&addr)[4][3]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
                  "+v"(v[10]), "+v"(v[11]));
+  // ((B | D') << 8) | (A | C') as v_or, v_or, v_lshl_or_b32: hipcc picks v_or, v_lshlrev, v_or3 (two quarter-rate-class
+  // instructions instead of one)
   Pack3 o;
-  o.a = ((v[1] | v[3]) << 8) | (v[0] | v[2]);
-  o.b = ((v[5] | v[7]) << 8) | (v[4] | v[6]);
-  o.c = ((v[9] | v[11]) << 8) | (v[8] | v[10]);
+  o.a = lshl8_or(v[1] | v[3], v[0] | v[2]);
+  o.b = lshl8_or(v[5] | v[7], v[4] | v[6]);
+  o.c = lshl8_or(v[9] | v[11], v[8] | v[10]);
   return o;
 }
 // the same lookups as separate values (a stage follows: the colour enhancer)
@@ -968,9 +975,16 @@ __device__ __forceinline__ void store12(__amdgpu_buffer_rsrc_t frame, unsigned o
 // Grey-world applyChannelGains (x * q) >> 8 on four packed bytes.  q <= 256 (the gains are normalised
 // by the largest one), so the products of the even and of the odd bytes stay inside their 16-bit
 // lanes and one 24-bit multiply serves two pixels.
+__device__ __forceinline__ uint32_t mul_u24_raw(uint32_t a, uint32_t b) {
+  // v_mul_u32_u24 reads bits 23:0 of both sources whatever the rest holds; through the builtin hipcc masks an operand it
+  // cannot prove small (the per-frame gain: three v_and_b32 per item)
+  uint32_t d;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ uint32_t gains_q8_swar(uint32_t v, unsigned q) {
-  const uint32_t pe = __umul24(v & 0x00FF00FFu, q);
-  const uint32_t po = __umul24((v >> 8) & 0x00FF00FFu, q);
+  const uint32_t pe = mul_u24_raw(v & 0x00FF00FFu, q);
+  const uint32_t po = mul_u24_raw((v >> 8) & 0x00FF00FFu, q);
   return bfi32(0xFF00FF00u, po, pe >> 8);
 }
 

@@ -241,6 +241,8 @@ void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream);
 // Returns false when the histogram launch failed: nothing after it was enqueued and the caller must not run the
 // state-advancing finalisation on stale data.
 bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t stream);
+// rip_probe.hip: one launch of a streaming microbenchmark (rip_debug_hbm_probe); returns the bytes it moves, 0 = unknown kind
+size_t launch_hbm_probe(int kind, const void* src, void* dst, size_t bytes, hipStream_t stream);
 // Turns raw statistics into FrameWb (grey-world / pca) or runs the ccc temporal filter + gains.
 void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
                         const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream,

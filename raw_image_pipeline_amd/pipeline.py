@@ -578,6 +578,16 @@ class RawImagePipeline:
         overrides once, when the handle is created)."""
         self._call("rip_set_tunable", name.encode(), int(value))
 
+    PROBE_KINDS = {"copy": 0, "read": 1, "fill": 2, "expand13": 3, "expand13_nt": 4, "copy12": 5}
+
+    def hbm_probe(self, kind, nbytes=1 << 30, reps=10):
+        """GB/s (best of ``reps`` launches, bytes read + written) of one of the library's hand-written streaming kernels on
+        this handle's device and stream (rip_debug_hbm_probe): the measured ceiling a kernel of that access shape can reach
+        on this box."""
+        out = C.c_double()
+        self._call("rip_debug_hbm_probe", int(self.PROBE_KINDS.get(kind, kind)), C.c_size_t(int(nbytes)), int(reps), C.byref(out))
+        return out.value
+
     KERNEL_CLASSES = ("stats", "ccc", "chain", "remap")
 
     def profile_begin(self, max_records):
