@@ -23,17 +23,23 @@ __global__ __launch_bounds__(kProbeBlock) void probe_copy_kernel(const u32x4* __
   const size_t i = (size_t)blockIdx.x * kProbeBlock + threadIdx.x;
   if (i < n16) dst[i] = src[i];
 }
-// read only: every lane folds its 16 bytes, one lane per wave writes the wave's fold (1 / 256 of the bytes read)
+// read only: every lane folds four 16-byte loads (all in flight together, a wave covers 4 x 1 KB), one lane per wave writes
+// the wave's fold (1 / 1024 of the bytes read).  One load per lane left the read rate at the workgroup launch rate.
+constexpr int kReadUnroll = 4;
 __global__ __launch_bounds__(kProbeBlock) void probe_read_kernel(const u32x4* __restrict__ src, uint32_t* __restrict__ sink, size_t n16) {
-  const size_t i = (size_t)blockIdx.x * kProbeBlock + threadIdx.x;
-  uint32_t v = 0;
-  if (i < n16) {
-    const u32x4 a = src[i];
-    v = a.x ^ a.y ^ a.z ^ a.w;
+  const size_t base = (size_t)blockIdx.x * (kProbeBlock * kReadUnroll) + threadIdx.x;
+  u32x4 a[kReadUnroll];
+#pragma unroll
+  for (int k = 0; k < kReadUnroll; k++) {
+    const size_t i = base + (size_t)k * kProbeBlock;
+    a[k] = i < n16 ? src[i] : u32x4{0u, 0u, 0u, 0u};
   }
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < kReadUnroll; k++) v ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
-  if ((threadIdx.x & 63) == 0) sink[i >> 6] = v;
+  if ((threadIdx.x & 63) == 0) sink[((size_t)blockIdx.x * kProbeBlock + threadIdx.x) >> 6] = v;
 }
 // write only
 __global__ __launch_bounds__(kProbeBlock) void probe_fill_kernel(u32x4* __restrict__ dst, size_t n16, uint32_t value) {
@@ -52,6 +58,23 @@ __global__ __launch_bounds__(kProbeBlock) void probe_expand13_kernel(const uint3
   else
     *reinterpret_cast<u32x3*>(dst + 3 * i) = o;
 }
+// the same 1 : 3 expand with 16 bytes in and 48 contiguous bytes out per lane (three 16-byte stores): the shape a 16-pixel-wide
+// demosaic item would have
+__global__ __launch_bounds__(kProbeBlock) void probe_expand13_wide_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16, int nt) {
+  const size_t i = (size_t)blockIdx.x * kProbeBlock + threadIdx.x;
+  if (i >= n16) return;
+  const u32x4 v = src[i];
+  const u32x4 a = {v.x, v.x ^ 1u, v.x ^ 2u, v.y}, b = {v.y ^ 1u, v.y ^ 2u, v.z, v.z ^ 1u}, c = {v.z ^ 2u, v.w, v.w ^ 1u, v.w ^ 2u};
+  if (nt) {
+    __builtin_nontemporal_store(a, dst + 3 * i);
+    __builtin_nontemporal_store(b, dst + 3 * i + 1);
+    __builtin_nontemporal_store(c, dst + 3 * i + 2);
+  } else {
+    dst[3 * i] = a;
+    dst[3 * i + 1] = b;
+    dst[3 * i + 2] = c;
+  }
+}
 // 3 : 3 copy in 12-byte lanes: the remap's store shape fed by a contiguous read (its gather replaced by a stream)
 __global__ __launch_bounds__(kProbeBlock) void probe_copy12_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n12) {
   const size_t i = (size_t)blockIdx.x * kProbeBlock + threadIdx.x;
@@ -69,8 +92,9 @@ size_t launch_hbm_probe(int kind, const void* src, void* dst, size_t bytes, hipS
       hipLaunchKernelGGL(probe_copy_kernel, blocks(bytes / 16), dim3(kProbeBlock), 0, stream, static_cast<const u32x4*>(src), static_cast<u32x4*>(dst), bytes / 16);
       return 2 * (bytes / 16 * 16);
     case 1:
-      hipLaunchKernelGGL(probe_read_kernel, blocks(bytes / 16), dim3(kProbeBlock), 0, stream, static_cast<const u32x4*>(src), static_cast<uint32_t*>(dst), bytes / 16);
-      return bytes / 16 * 16 + bytes / 16 / 64 * 4;
+      hipLaunchKernelGGL(probe_read_kernel, blocks((bytes / 16 + kReadUnroll - 1) / kReadUnroll), dim3(kProbeBlock), 0, stream, static_cast<const u32x4*>(src),
+                         static_cast<uint32_t*>(dst), bytes / 16);
+      return bytes / 16 * 16 + bytes / 16 / 64 / kReadUnroll * 4;
     case 2:
       hipLaunchKernelGGL(probe_fill_kernel, blocks(bytes / 16), dim3(kProbeBlock), 0, stream, static_cast<u32x4*>(dst), bytes / 16, 0x5a5a5a5au);
       return bytes / 16 * 16;
@@ -82,6 +106,11 @@ size_t launch_hbm_probe(int kind, const void* src, void* dst, size_t bytes, hipS
     case 5:
       hipLaunchKernelGGL(probe_copy12_kernel, blocks(bytes / 12), dim3(kProbeBlock), 0, stream, static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst), bytes / 12);
       return 2 * (bytes / 12 * 12);
+    case 6:
+    case 7:
+      hipLaunchKernelGGL(probe_expand13_wide_kernel, blocks(bytes / 16), dim3(kProbeBlock), 0, stream, static_cast<const u32x4*>(src), static_cast<u32x4*>(dst), bytes / 16,
+                         kind == 7 ? 1 : 0);
+      return 4 * (bytes / 16 * 16);
     default:
       return 0;
   }

@@ -9,7 +9,7 @@ branches that the benchmark never takes (debayered tap, non-zero colour bias, ab
 are inside the loop too; they are listed separately by the marker instructions they contain and subtracted for the
 `executed` figure.  `--pmc-valu-per-wave N` (SQ_INSTS_VALU / SQ_WAVES of the same launch) cross-checks the executed count.
 
-usage: chain_ledger.py [--clock GHz] [--pmc workload=valu_per_wave,iterations_per_wave ...]"""
+usage: chain_ledger.py [--clock GHz] [--pmc workload=valu_per_wave,iterations_per_wave ...] [--measured workload=valu_per_item ...]"""
 import collections
 import json
 import os
@@ -88,11 +88,16 @@ def price(blocks):
 def main():
     clock = 2.1
     pmc = {}
+    measured = {}  # --measured workload=valu_per_item: the two-point hardware count
     args = sys.argv[1:]
     while args:
         a = args.pop(0)
         if a == "--clock":
             clock = float(args.pop(0))
+        elif a == "--measured":
+            while args and "=" in args[0]:
+                k, v = args.pop(0).split("=")
+                measured[k] = float(v)
         elif a == "--pmc":
             while args and "=" in args[0]:
                 k, v = args.pop(0).split("=")
@@ -115,6 +120,18 @@ def main():
             rare = [b for i, b in enumerate(blocks) if i in bracketed or any(re.search(r"0x4ded21", t) for t in b["ins"]) or
                     sum(1 for t in b["ins"] if t.startswith("v_add_f32") and ic.SGPR_SRC.search(t.split(",", 1)[1])) >= 3 or
                     sum(1 for t in b["ins"] if t.startswith("v_perm_b32")) >= 6 and any("buffer_store_dwordx3" in t for t in b["ins"])]
+            # a forward branch that skips a run of blocks holding a never-taken block skips all of them (the per-lane compare /
+            # exec-mask blocks in front of the abToXZ linear segment, the flow blocks around the colour-bias adds)
+            index = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
+            rare_idx = set(i for i, b in enumerate(blocks) if any(b is r for r in rare))
+            by_content = set(rare_idx)
+            for i, b in enumerate(blocks):
+                m = re.match(r"s_cbranch_(vccz|vccnz|scc0|scc1)\s+(\.LBB\d+_\d+)", b["ins"][-1]) if b["ins"] else None
+                j = index.get(m.group(2)) if m else None
+                # short skips only: the long forward branches of the loop lead to out-of-line blocks, not around a rare one
+                if j is not None and i + 1 < j <= i + 16 and any(k in by_content for k in range(i + 1, j)):
+                    rare_idx.update(range(i + 1, j))
+            rare = [b for i, b in enumerate(blocks) if i in rare_idx]
             cyc, cnt, lds = price(blocks)
             rcyc, rcnt, rlds = price(rare)
             valu = sum(v for k, v in cnt.items() if k.startswith("v_"))
@@ -133,9 +150,22 @@ def main():
                   % (valu, tot, rvalu, rtot, valu - rvalu, tot - rtot))
             print("   per pixel-wave: %.1f VALU issue cycles, %.1f LDS cycles (conflict-free), %d LDS / %d SALU instructions per item"
                   % ((tot - rtot) / 8, (lds - rlds) / 8.0, rec["lds_instr_per_item"], rec["salu_instr_per_item"]))
-            for k, v in sorted(cyc.items(), key=lambda kv: -kv[1])[:28]:
+            # per-opcode table of the blocks that are NOT recognised as never-taken (round 4: the table used to be the static
+            # listing, which made the colour-bias adds, the 16 compares of the abToXZ linear segment and the other three
+            # demosaic patterns look like executed work).  Still static inside those blocks: the four-way Bayer-pattern switch
+            # contributes the merges of all patterns (about 60 instructions per item, 18 of them v_perm_b32) of which one
+            # pattern's share runs -- the hardware count (`measured_valu_per_item`, two-point PMC measurement) is the
+            # executed figure.
+            rare_ids = set(id(b) for b in rare)
+            ecyc, ecnt, _ = price([b for b in blocks if id(b) not in rare_ids])
+            if wl in measured:
+                rec["measured_valu_per_item"] = measured[wl]
+                print("   executed per item, measured (SQ_INSTS_VALU at 16 and 8 frames per visit, setup separated): %.0f VALU instructions"
+                      % measured[wl])
+            print("   per opcode, never-taken blocks excluded:")
+            for k, v in sorted(ecyc.items(), key=lambda kv: -kv[1])[:28]:
                 if v:
-                    print("      %-36s n=%-4d cycles=%.0f" % (k, cnt[k], v))
+                    print("      %-36s n=%-4d cycles=%.0f" % (k, ecnt[k], v))
     with open(os.path.join(ROOT, "profiles", "chain_ledger.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")
