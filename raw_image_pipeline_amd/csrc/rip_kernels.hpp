@@ -212,7 +212,7 @@ struct RemapPlanBuildParams {
 };
 void launch_remap_plan_build(const RemapPlanBuildParams& p, hipStream_t stream);
 
-// Launch tunables.  The defaults are the measured optima; the environment variables named beside them
+// Launch tunables.  The defaults are the measured optima (sweeps in EXPERIMENTS.md); the environment variables named beside them
 // override them for experiments, and are read ONCE, by tunables_from_env() when a handle is created -- never on a launch path.
 struct Tunables {
   int chain_blocks = 0;       // RIP_CHAIN_BLOCKS: persistent 256-thread workgroups per launch; 0 = 2048 (4096 for the 512-thread variants)

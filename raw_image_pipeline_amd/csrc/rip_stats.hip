@@ -369,7 +369,7 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
         int last = a == 0 ? s_state.uv_x : s_state.uv_y;
         // The gain does not see the data: p -> p' depends on (h, r) only.  Two cases keep the IEEE division (a dozen
         // dependent instructions on a single lane) out of most steps without changing a bit of the result:
-        //  * h == 0 -- the filter the reference's pipeline actually runs (the one-argument constructor
+        //  * h == 0 -- the filter the reference's pipeline actually runs (PARITY.md: the one-argument constructor
         //    leaves a default cv::KalmanFilter) -- gives t2 = +0, k = +0 / r = +0, p' = p + 1 and x' = x + 0 * innov = x;
         //  * otherwise the covariance runs into a fixed point of the float iteration after a few dozen frames, and from
         //    then on recomputing k would reproduce the same value.

@@ -4,7 +4,7 @@ The oracle (and the HIP kernels) implement the uncontracted sequence: every prod
 contract `a*b + c` into one fma wherever the target has one (every aarch64 build -- the reference's Jetson target --, the
 AVX2 / FMA3 dispatch variants on x86-64), so a given OpenCV binary may round differently.  This file measures the
 difference between the oracle's three contraction models (oracle/rip_oracle.c: 0 none, 1 GCC / Clang order, 2 the other
-association) stage by stage, exhaustively where the domain allows, and asserts the bound DESIGN.md section 4 and BASELINE.md
+association) stage by stage, exhaustively where the domain allows, and asserts the bound PARITY.md and BASELINE.md
 section 4 state: at most 1 LSB at the output of the stage that contains the float expression.  The counts are printed
 (pytest -s) and are the numbers quoted in DESIGN.md.  CPU only."""
 import os

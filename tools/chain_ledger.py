@@ -88,7 +88,7 @@ def price(blocks):
 def main():
     clock = 2.1
     pmc = {}
-    measured = {}  # --measured workload=valu_per_item: the two-point hardware count
+    measured = {}  # --measured workload=valu_per_item: the two-point hardware count (EXPERIMENTS.md, round 4)
     args = sys.argv[1:]
     while args:
         a = args.pop(0)
