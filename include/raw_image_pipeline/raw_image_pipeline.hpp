@@ -251,6 +251,13 @@ class RawImagePipeline {
   Mat getDistColorImage() const { return image(RIP_IMAGE_COLOR); }
   Mat getRectMask() const { return image(RIP_IMAGE_RECT_MASK); }
   Mat getProcessedImage() const { return image(RIP_IMAGE_PROCESSED); }
+  // Not in the reference: the same three images without a copy for a frame that came through collect() / collectView() --
+  // the taps travel with the result into the handle's pinned host memory (rip_get_image_view), so a publisher that serialises
+  // the image at once needs no second device read and no memcpy.  Valid until the next collect*() on this object; frames of
+  // apply() / process() only exist on the device and come back as a copy, like the getters above.
+  Mat getDistDebayeredImageView() const { return image_view(RIP_IMAGE_DEBAYERED); }
+  Mat getDistColorImageView() const { return image_view(RIP_IMAGE_COLOR); }
+  Mat getProcessedImageView() const { return image_view(RIP_IMAGE_PROCESSED); }
 
   // access for callers that want the device-resident batch API (rip_apply_device)
   rip_pipeline* handle() const { return h_; }
@@ -293,6 +300,14 @@ class RawImagePipeline {
     Mat out = detail::make_u8(rows, cols, cn);
     check(rip_get_image(h_, which, detail::bytes(out), (size_t)rows * cols * cn, &rows, &cols, &cn));
     return out;
+  }
+  Mat image_view(int which) const {
+    int rows = 0, cols = 0, cn = 0;
+    const uint8_t* view = nullptr;
+    check(rip_get_image_view(h_, which, &view, &rows, &cols, &cn));
+    if (rows == 0 || cols == 0) return Mat();
+    if (!view) return image(which);
+    return detail::wrap_u8(rows, cols, cn, const_cast<uint8_t*>(view));
   }
   Mat matrix(rip_status (*fn)(const rip_pipeline*, double*), int rows, int cols) const {
     Mat m = detail::make_f64(rows, cols);

@@ -94,6 +94,10 @@ int main(int argc, char** argv) {
     Mat v1 = proc.collectView(t1, e1);
     if (e1 != "bgr8" || v1.rows != h || v1.cols != w || v1.channels() != 3) return fail("collectView geometry");
     if (std::memcmp(v1.data, out.data, (size_t)w * h * 3) != 0) return fail("collectView != process");
+    // the taps of the collected frame as views of the slot's pinned buffers: same pixels as the copies of the process() frame
+    Mat tv = proc.getDistDebayeredImageView(), cv2 = proc.getDistColorImageView(), pv = proc.getProcessedImageView();
+    if (tv.rows != h || cv2.rows != h || pv.data != v1.data) return fail("tap views after collectView");
+    if (std::memcmp(tv.data, tap.data, (size_t)w * h * 3) != 0 || std::memcmp(cv2.data, col.data, (size_t)w * h * 3) != 0) return fail("tap views != taps");
     Mat c2 = proc.collect(t2, e2);
     if (e2 != "bgr8" || std::memcmp(c2.data, out.data, (size_t)w * h * 3) != 0) return fail("collect != process");
     try {
