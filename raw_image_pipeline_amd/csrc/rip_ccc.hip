@@ -217,15 +217,28 @@ __device__ __forceinline__ CccSampleGeom ccc_sample_geom(const CccParams& p, con
     g.b0 = tb.ibeta[dy * 2];
     g.b1 = tb.ibeta[dy * 2 + 1];
   }
+  const bool block = y1 == g.y + 1 && x1 == g.x + 1;
+  if (p.flip_angle == 180) {  // uniform
+    // The estimator samples the image AFTER the flip (white_balance follows flip in pipeline<T>(), raw_image_pipeline.hpp:
+    // 143-177).  Post-flip pixel (y, x) is source pixel (rows - 1 - y, cols - 1 - x), so the 2x2 block {y, y + 1} x {x, x + 1}
+    // is the source block whose top-left pixel is (rows - 2 - y, cols - 2 - x), read upside down and mirrored: the row weights
+    // and the two column weights change places, the demosaic runs on source coordinates (its parities are the frame's).
+    g.y = s.rows - 2 - g.y;
+    g.x = s.cols - 2 - g.x;
+    const int t = g.b0;
+    g.b0 = g.b1;
+    g.b1 = t;
+    g.alpha2 = (g.alpha2 >> 16) | (g.alpha2 << 16);
+  }
   // the two dwords of a window row end at most at byte x + 6 of that row: past the row's end that is the next row of the
   // frame, except in the frame's last row (y + 2 == rows - 1), where it could leave the buffer
-  g.straight = y1 == g.y + 1 && x1 == g.x + 1 && g.y >= 1 && y1 <= s.rows - 2 && g.x >= 1 && x1 <= s.cols - 2 &&
+  g.straight = block && g.y >= 1 && g.y + 1 <= s.rows - 2 && g.x >= 1 && g.x + 1 <= s.cols - 2 &&
                ((unsigned)(g.x + 6) < (unsigned)s.step || g.y + 2 < s.rows - 1);
   return g;
 }
 // frame-level part of fetch_block2x2's window-path condition (wave-uniform)
 __device__ __forceinline__ bool ccc_frame_straight(const CccParams& p, const SrcView& s) {
-  return s.kind == SRC_BAYER && p.flip_angle == 0 && (reinterpret_cast<uintptr_t>(s.base) & 3u) == 0 && (s.step & 3u) == 0 &&
+  return s.kind == SRC_BAYER && (p.flip_angle == 0 || p.flip_angle == 180) && (reinterpret_cast<uintptr_t>(s.base) & 3u) == 0 && (s.step & 3u) == 0 &&
          (unsigned long long)s.step * (unsigned long long)s.rows < (1ull << 32) && s.step < (1u << 24);
 }
 

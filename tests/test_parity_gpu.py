@@ -451,7 +451,8 @@ def test_config3_full_size_1920x1200_ccc_batch(gpu_pipe, oracle):
         assert_images_equal(out[i], ref, "config3 frame %d" % i, TOL_DECLARED)
 
 
-@pytest.mark.parametrize("size,pattern,flip", [((384, 240), "bayer_gbrg8", 0), ((720, 540), "bayer_rggb8", 180), ((250, 190), "bayer_bggr8", 90)])
+@pytest.mark.parametrize("size,pattern,flip", [((384, 240), "bayer_gbrg8", 0), ((720, 540), "bayer_rggb8", 180), ((250, 190), "bayer_bggr8", 90),
+                                               ((1000, 700), "bayer_grbg8", 180), ((500, 334), "bayer_gbrg8", 180), ((612, 512), "bayer_rggb8", 180)])
 def test_ccc_lds_histogram_path(gpu_pipe, oracle, monkeypatch, size, pattern, flip):
     """Batches take the estimator whose histogram is accumulated in LDS (two workgroups per frame, no global atomics, no
     memset, 16-bit counters with wrap repair); small batches the atomic one.  Forced on here for a short batch: every frame equals the oracle, and equals
