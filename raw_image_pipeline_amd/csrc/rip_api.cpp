@@ -718,7 +718,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     }
     chain_step = mid_pitch;
     chain_stride = mid_frame;
-    if (p->use_tiled_remap && pl.channels == 3) {
+    if (p->use_tiled_remap && (pl.channels == 3 || pl.channels == 1)) {
       ensure_plan(p, pl.mid_rows, pl.mid_cols);
       tiled = true;
     }

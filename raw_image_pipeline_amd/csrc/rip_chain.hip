@@ -390,6 +390,53 @@ __global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, Item
 }
 
 // ------------------------------------------------------------------------------------------------
+// mono8 input (the reference passes single-channel frames through: debayer.cpp:45-79 only converts Bayer and rgb8, flip.cpp
+// and cv::LUT are channel-agnostic, every colour module is skipped or asserts on one channel): flip 0 / 180 + gamma LUT, four
+// pixels (one dword) per lane in and out, the 256-byte table in LDS.  1 B/px in, 1 B/px out.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void chain_mono_kernel(ChainParams p, ItemMap im, int items_per_frame) {
+  __shared__ uint8_t s_gamma[256];
+  const bool gam = (p.stage_bits & ST_GAMMA) != 0;
+  s_gamma[threadIdx.x] = gam ? p.tabs->gamma_lut[threadIdx.x] : (uint8_t)threadIdx.x;
+  __syncthreads();
+  const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
+  const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
+  const bool flip180 = p.flip_angle == 180;
+  const bool dst_nt = p.dst_streaming != 0;
+  const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
+  const unsigned dst_bytes = __umul24((unsigned)(p.drows - 1), (unsigned)p.dst_step) + (unsigned)p.dcols;
+  const unsigned tap_bytes = __umul24((unsigned)p.drows, (unsigned)p.dcols);
+  for (int chunk = blockIdx.x; chunk < chunks_per_frame; chunk += gridDim.x) {
+    const int item = chunk * kBlock + threadIdx.x;
+    if (item >= items_per_frame) continue;
+    int ys, grp;
+    im.split(item, ys, grp);
+    const int x0 = grp * 4;
+    const int yd = flip180 ? p.rows - 1 - ys : ys;
+    const int xbase = flip180 ? p.cols - 4 - x0 : x0;
+    const unsigned src_off = __umul24((unsigned)ys, (unsigned)p.src_step) + (unsigned)x0;
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase;
+    const unsigned tap_off = __umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase;
+    for (int frame = f_begin; frame < f_end; frame++) {
+      const __amdgpu_buffer_rsrc_t src = frame_rsrc(p.src + (size_t)frame * p.src_frame_stride, src_bytes);
+      const __amdgpu_buffer_rsrc_t dst = frame_rsrc(p.dst + (size_t)frame * p.dst_frame_stride, dst_bytes);
+      uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(src, (int)src_off, 0, 0);
+      if (flip180) v = __builtin_bswap32(v);  // the group is written mirrored: reverse the four pixels
+      if (p.tap) __builtin_amdgcn_raw_buffer_store_b32(v, frame_rsrc(p.tap + (size_t)frame * p.tap_frame_stride, tap_bytes), (int)tap_off, 0, 0);
+      if (gam) {
+        const uint32_t a = s_gamma[v & 0xFFu], b = s_gamma[(v >> 8) & 0xFFu], c = s_gamma[(v >> 16) & 0xFFu], d = s_gamma[v >> 24];
+        v = a | (b << 8) | (c << 16) | (d << 24);
+      }
+      if (dst_nt)
+        __builtin_amdgcn_raw_buffer_store_b32(v, dst, (int)dst_off, 0, 2);
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(v, dst, (int)dst_off, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bayer input with a 90 / 270 degree flip (flip.cpp:45-60: transpose + flip == cv::rotate).  Same
 // window / SWAR demosaic / per-pixel stages as chain_fast_kernel, stage set decided at run time.  A
 // 4x2 item lands as four 2-pixel (6-byte) pieces in four output rows, so the lanes of a workgroup are
@@ -540,6 +587,14 @@ int chain_uses_fast_path(const ChainParams& p) {
          p.dst_frame_stride % 4 == 0 && aligned4(p.dst) && (!p.tap || (aligned4(p.tap) && p.tap_frame_stride % 4 == 0));
 }
 
+bool chain_uses_mono_path(const ChainParams& p) {
+  return p.src_kind == SRC_MONO && p.channels == 1 && (p.flip_angle == 0 || p.flip_angle == 180) && p.cols % 4 == 0 && p.src_step % 4 == 0 &&
+         p.src_frame_stride % 4 == 0 && aligned4(p.src) && p.src_step < (1u << 24) && p.rows < (1 << 23) &&
+         (unsigned long long)p.src_step * (unsigned long long)p.rows < (1ull << 32) && p.dst_step % 4 == 0 && p.dst_step < (1u << 24) &&
+         (unsigned long long)p.dst_step * (unsigned long long)p.drows < (1ull << 32) && p.dst_frame_stride % 4 == 0 && aligned4(p.dst) &&
+         (!p.tap || (aligned4(p.tap) && p.tap_frame_stride % 4 == 0));
+}
+
 bool chain_uses_rot_path(const ChainParams& p) {
   return bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind) &&
          (p.flip_angle == 90 || p.flip_angle == 270) && p.channels == 3 && p.drows == p.cols && p.dcols == p.rows &&
@@ -621,6 +676,15 @@ void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream) 
     const int blocks = std::min(2048, chunks);
     const int groups = frame_groups(p, tn, 2048, blocks);
     hipLaunchKernelGGL(chain_color_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, im, items);
+    return;
+  }
+  if (chain_uses_mono_path(p)) {
+    ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
+    const int items = p.rows * (p.cols / 4);
+    const int chunks = (items + kBlock - 1) / kBlock;
+    const int blocks = std::min(8192, chunks);
+    const int groups = frame_groups(p, tn, 8192, blocks);  // memory-rate: two (four with the gamma table) frames per visit
+    hipLaunchKernelGGL(chain_mono_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, im, items);
     return;
   }
   long long npix = (long long)p.drows * p.dcols;

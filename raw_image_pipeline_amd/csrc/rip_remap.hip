@@ -125,9 +125,14 @@ __global__ __launch_bounds__(kBlock) void remap_vec4_kernel(RemapParams p, ItemM
 // (top * wy0 + bot * wy1) >> 10 with both products on the 24-bit multiplier: one v_mul_u32_u24 + one v_mad_u32_u24.
 // Written out because hipcc proves the operands small, turns the builtins into plain multiplies and then selects the
 // quarter-rate v_mul_lo_u32 for a quarter of them (6 of the 24 per lane and frame).
+// `top` / `bot` come straight out of v_dot4_u32_u8.  On gfx90a and later a dot instruction's result needs THREE wait states
+// before a different VALU instruction may read it (LLVM GCNHazardRecognizer: DotWriteDifferentVALURead); the compiler pads
+// that for the instructions it emits, but it does not look inside inline assembly -- hence the s_nop 2 in front.  (Found in
+// round 4: the one-channel gather, where nothing else sat between the dot and the multiply, read stale registers; the
+// colour gathers had exactly three instructions in between by luck of the schedule.)
 __device__ __forceinline__ int blend_rows(unsigned top, unsigned wy0, unsigned bot, unsigned wy1) {
   unsigned acc;
-  asm("v_mul_u32_u24 %0, %1, %2\n\tv_mad_u32_u24 %0, %3, %4, %0" : "=&v"(acc) : "v"(top), "v"(wy0), "v"(bot), "v"(wy1));
+  asm("s_nop 2\n\tv_mul_u32_u24 %0, %1, %2\n\tv_mad_u32_u24 %0, %3, %4, %0" : "=&v"(acc) : "v"(top), "v"(wy0), "v"(bot), "v"(wy1));
   return (int)(acc >> 10);
 }
 __device__ __forceinline__ void lds_load6(const uint8_t* lds, unsigned a, uint32_t& lo, uint32_t& hi) {
@@ -135,6 +140,12 @@ __device__ __forceinline__ void lds_load6(const uint8_t* lds, unsigned a, uint32
   const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
   lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
   hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+}
+
+// four bytes starting at LDS byte address a (any alignment): two aligned dwords realigned
+__device__ __forceinline__ uint32_t lds_load4(const uint8_t* lds, unsigned a) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(lds + (a & ~3u));
+  return __builtin_amdgcn_alignbyte(w[1], w[0], a & 3u);
 }
 
 // Destination pixels whose taps straddle the image border (a few thousand per map) are listed by the
@@ -149,6 +160,12 @@ __global__ __launch_bounds__(kBlock) void remap_border_kernel(RemapTiledParams p
   const float2 m = reinterpret_cast<const float2*>(b.map_xy)[__umul24((unsigned)yd, (unsigned)b.dcols) + (unsigned)xd];
   const int frame = blockIdx.y;
   const RemapSrc s = remap_src(b, frame);
+  if (b.channels == 1) {  // uniform
+    int q[1];
+    remap_pixel<1>(s, m.x, m.y, q);
+    b.dst[(size_t)frame * b.dst_frame_stride + (__umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd)] = (uint8_t)q[0];
+    return;
+  }
   int q[3];
   remap_pixel<3>(s, m.x, m.y, q);
   uint8_t* d = b.dst + (size_t)frame * b.dst_frame_stride + (__umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u);
@@ -316,7 +333,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 
-template <int PRE>
+// CN: channels of the image (3: interleaved BGR; 1: mono8 frames, which the reference passes through flip, gamma and
+// undistortion unchanged in layout).  The plan -- source rectangles in pixels, 1/32-px tap words -- does not depend on it.
+template <int PRE, int CN>
 __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr unsigned kStage = (unsigned)PRE * kRemapTileThreads * 16u;  // bytes per stage
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
   const int nb = p.stages, dist = nb - 1;  // ring size, prefetch distance (2 or 3)
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);
   const unsigned wave_chunk0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);
-  const unsigned dst_bytes = __umul24((unsigned)(b.drows - 1), (unsigned)b.dst_step) + (unsigned)b.dcols * 3u;
+  const unsigned dst_bytes = __umul24((unsigned)(b.drows - 1), (unsigned)b.dst_step) + (unsigned)b.dcols * (unsigned)CN;
   for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
     const int tile = xcd * per_xcd + ti;
     if (tile >= ntiles) break;
@@ -343,9 +362,9 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
     const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
     const int yd = ty * kRemapTileH + lrow, xd = tx * kRemapTileW + lgrp * 4;
     const bool in_image = yd < b.drows && xd < b.dcols;
-    const unsigned xbyte0 = (unsigned)d.x0 * 3u;
+    const unsigned xbyte0 = (unsigned)d.x0 * (unsigned)CN;
     const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
-    const unsigned pitch = (ph + (unsigned)d.w * 3u + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes
+    const unsigned pitch = (ph + (unsigned)d.w * (unsigned)CN + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes (CN == 3)
     const unsigned chunks = pitch >> 4;
     const unsigned total = d.w > 0 ? chunks * (unsigned)d.h : 0u;
     const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
@@ -366,11 +385,11 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
       const uint32_t w = words[k];
       const bool live = w < kPlanBorder;
       const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u, fy = w >> 27;
-      tap_addr[k] = live ? __umul24(rely, pitch) + relx * 3u + ph : 0u;
+      tap_addr[k] = live ? __umul24(rely, pitch) + relx * (unsigned)CN + ph : 0u;
       wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
       wyy[k] = (32u - fy) | (fy << 16);
     }
-    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u;
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * (unsigned)CN;
 
     auto issue = [&](int f, int slot) {
       const RemapSrc s = remap_src(b, f);
@@ -381,6 +400,22 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
     };
     auto gather_store = [&](const uint8_t* buf, int f) {
       if (!in_image) return;
+      if constexpr (CN == 1) {
+        // one byte per tap: the two taps of a row are the low bytes of the realigned dword, the x weights bytes 0 and 1 of
+        // wxb (byte 3, the colour kernel's place for fx, is moved down once per tile below), so a row sum is one v_dot4
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t tl = lds_load4(buf, tap_addr[k]), bl = lds_load4(buf, tap_addr[k] + pitch);
+          const unsigned wy0 = wyy[k] & 0xffffu, wy1 = wyy[k] >> 16;
+          const unsigned w2 = (wxb[k] & 0xffu) | ((wxb[k] >> 16) & 0xff00u);
+          const unsigned top = __builtin_amdgcn_udot4(tl, w2, 16u, false);
+          const unsigned bot = __builtin_amdgcn_udot4(bl, w2, 16u, false);
+          out |= (uint32_t)blend_rows(top, wy0, bot, wy1) << (8 * k);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(out, frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), (int)dst_off, 0, 0);
+        return;
+      }
       uint32_t t0[4], t1[4], b0[4], b1[4];  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -458,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void remap_generic_kernel(RemapParams p) {
 bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream) {
   const RemapParams& b = p.base;
   if (b.n_frames <= 0) return true;
-  const bool ok = b.channels == 3 && b.dcols % 4 == 0 && b.dst_step % 4 == 0 && b.dst_frame_stride % 4 == 0 && aligned4(b.dst) &&
+  const bool ok = (b.channels == 3 || b.channels == 1) && b.dcols % 4 == 0 && b.dst_step % 4 == 0 && b.dst_frame_stride % 4 == 0 && aligned4(b.dst) &&
                   b.src_step % 16 == 0 && b.src_frame_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(b.src) & 15u) == 0 &&
                   (reinterpret_cast<uintptr_t>(p.words) & 15u) == 0 && b.src_step < (1u << 24) && b.rows < (1 << 23) &&
                   (unsigned long long)b.src_step * (unsigned long long)b.rows < (1ull << 32) && b.dst_step < (1u << 24) &&
@@ -474,6 +509,9 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
   // measured on config2 (sweeps in DESIGN.md): 3 stages (two frames ahead) with 4 workgroups per CU; more resident
   // workgroups fetch more (the source rectangles of neighbouring tiles stop meeting in L2) and run slower
   const int stages_env = tn.remap_stages;
+  // one-channel frames run the ring kernel only (PRE chosen from the three-channel footprint of the plan: an upper bound of
+  // the one-channel one, the surplus lanes load from an out-of-range offset, i.e. nothing)
+  if (b.channels == 1 && !(ring_env && chunks <= 4u * kRemapTileThreads)) return false;
   if (ring_env && chunks <= 4u * kRemapTileThreads) {
     // LDS-DMA ring: PRE chunks per lane and frame, `stages` buffers of PRE * 4 KiB
     const int pre = chunks <= 1u * kRemapTileThreads ? 1 : (chunks <= 2u * kRemapTileThreads ? 2 : 4);
@@ -499,12 +537,19 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
     int groups = std::max((256 * per_cu) / blocks, (b.n_frames + frames_per_visit - 1) / frames_per_visit);
     groups = std::max(1, std::min(b.n_frames, groups));
     const dim3 grid(blocks, groups);
-    if (pre == 1)
-      hipLaunchKernelGGL(remap_ring_kernel<1>, grid, dim3(kRemapTileThreads), lds, stream, q);
+    if (b.channels == 1) {
+      if (pre == 1)
+        hipLaunchKernelGGL((remap_ring_kernel<1, 1>), grid, dim3(kRemapTileThreads), lds, stream, q);
+      else if (pre == 2)
+        hipLaunchKernelGGL((remap_ring_kernel<2, 1>), grid, dim3(kRemapTileThreads), lds, stream, q);
+      else
+        hipLaunchKernelGGL((remap_ring_kernel<4, 1>), grid, dim3(kRemapTileThreads), lds, stream, q);
+    } else if (pre == 1)
+      hipLaunchKernelGGL((remap_ring_kernel<1, 3>), grid, dim3(kRemapTileThreads), lds, stream, q);
     else if (pre == 2)
-      hipLaunchKernelGGL(remap_ring_kernel<2>, grid, dim3(kRemapTileThreads), lds, stream, q);
+      hipLaunchKernelGGL((remap_ring_kernel<2, 3>), grid, dim3(kRemapTileThreads), lds, stream, q);
     else
-      hipLaunchKernelGGL(remap_ring_kernel<4>, grid, dim3(kRemapTileThreads), lds, stream, q);
+      hipLaunchKernelGGL((remap_ring_kernel<4, 3>), grid, dim3(kRemapTileThreads), lds, stream, q);
   } else {
     // rectangles larger than 4 * kRemapTileThreads chunks (strong local magnification) or RIP_REMAP_RING=0 (A/B runs)
     int pre = !ring_env && b.n_frames >= 2 && chunks <= 2u * kRemapTileThreads ? 2 : 0;

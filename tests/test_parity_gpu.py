@@ -775,3 +775,28 @@ def test_submit_reads_a_pageable_5_MB_frame_before_it_returns(rip_lib):
     # frames of the synchronous path have no host view: the getter falls back to the device read
     pipe.process(frames[0], "bayer_rggb8")
     assert_images_equal(pipe.get_dist_color_image(copy=False), want_col[0], "tap of a process() frame through the view getter")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(64, 48), (132, 36), (640, 480), (2448, 2048)])
+@pytest.mark.parametrize("angle,gamma,undistort", [(0, False, False), (180, True, False), (0, True, True), (180, False, True), (180, True, True)])
+def test_mono8_fast_path_flip_gamma_undistortion(gpu_pipe, oracle, size, angle, gamma, undistort):
+    """mono8 frames (the reference passes single-channel images through flip, the gamma LUT and undistortion; every colour
+    module is skipped or asserts: debayer.cpp:45-79, flip.cpp:45-62, gamma_correction.cpp, undistortion.cpp:240-249) on the
+    dword-per-lane chain kernel and the one-channel LDS-DMA ring remap: single frames with taps, then a resident batch."""
+    import torch
+    w, h = size
+    c = cfg(flip=angle != 0, flip_angle=angle, gamma=gamma, gamma_k=0.8, undistort=undistort, cam=synth.camera_model(w, h), balance=0.2, fov_scale=1.1)
+    frames = [synth.gen_frame(w, h, "bayer_rggb8", seed=4200 + i, kind="scene" if i else "uniform") for i in range(3)]  # any one-channel image
+    singles = []
+    for i, f in enumerate(frames):
+        got = run_both(gpu_pipe, oracle, c, f, "mono8", TOL_INTERP, what="mono8 %s flip %d gamma %s undistort %s frame %d" % (size, angle, gamma, undistort, i))
+        singles.append(got)
+        ref_taps = oracle_run(oracle, c, f, "mono8", taps=True)
+        assert_images_equal(gpu_pipe.get_processed_image().reshape(got.shape), got, "processed tap")
+        if undistort:  # the pre-undistortion image (dist_image_): flipped and gamma-corrected, not remapped
+            assert_images_equal(gpu_pipe.get_dist_color_image().reshape(h, w), np.asarray(ref_taps[3])[:h * w].reshape(h, w), "mono colour tap")
+    dev = torch.from_numpy(np.stack([frames[i % 3] for i in range(7)])).cuda()
+    out = gpu_pipe.apply_device(dev, "mono8").cpu().numpy()
+    for i in range(7):
+        assert_images_equal(out[i].reshape(singles[i % 3].shape), singles[i % 3], "mono8 batch frame %d" % i)
