@@ -25,12 +25,18 @@ struct StatAcc {
   unsigned m[3];
 };
 
+// SimpleWB histograms in LDS: kHistRep interleaved copies of the 3 x 256 bins, lane l counts in copy l % kHistRep.
+// Neighbouring pixels mostly fall into the same few bins, and LDS atomics of one instruction that hit the same address are
+// served one after the other: with one copy a wave's 64 increments of a flat region take 64 LDS cycles, with eight copies
+// (consecutive dwords = consecutive banks: no conflict between the copies) eight.  24 KB per workgroup.
+constexpr int kHistRep = 8, kHistRepShift = 3;
+constexpr int kHistWordsLds = 768 * kHistRep;
 __device__ __forceinline__ void stat_add(const StatsParams& p, int b, int g, int r, StatAcc& a, unsigned* s_hist) {
   if (p.mode == WB_SIMPLE) {
-    // SimpleWB: per-channel 256-bin histograms, privatised in LDS
-    atomicAdd(&s_hist[b], 1u);
-    atomicAdd(&s_hist[256 + g], 1u);
-    atomicAdd(&s_hist[512 + r], 1u);
+    const unsigned copy = threadIdx.x & (kHistRep - 1);
+    atomicAdd(&s_hist[((unsigned)b << kHistRepShift) + copy], 1u);
+    atomicAdd(&s_hist[((256u + (unsigned)g) << kHistRepShift) + copy], 1u);
+    atomicAdd(&s_hist[((512u + (unsigned)r) << kHistRepShift) + copy], 1u);
   } else if (p.mode == WB_Q8) {
     // GrayworldWB calculateChannelSums: skip when (max-min)*255 > thresh255*max
     unsigned mn = (unsigned)min(b, min(g, r)), mx = (unsigned)max(b, max(g, r));
@@ -52,7 +58,7 @@ __device__ __forceinline__ void stat_add(const StatsParams& p, int b, int g, int
 
 __device__ __forceinline__ void stat_hist_init(const StatsParams& p, unsigned* s_hist) {
   if (p.mode != WB_SIMPLE) return;
-  for (int i = threadIdx.x; i < 768; i += kBlock) s_hist[i] = 0u;
+  for (int i = threadIdx.x; i < kHistWordsLds; i += kBlock) s_hist[i] = 0u;
   __syncthreads();
 }
 
@@ -99,7 +105,12 @@ __device__ __forceinline__ void stat_flush(const StatsParams& p, StatAcc& a, Fra
   if (p.mode == WB_SIMPLE) {
     __syncthreads();
     for (int i = threadIdx.x; i < 768; i += kBlock)
-      if (s_hist[i]) atomicAdd(&p.hist3[(size_t)frame * 768 + i], s_hist[i]);
+    {
+      unsigned n = 0;
+#pragma unroll
+      for (int c = 0; c < kHistRep; c++) n += s_hist[i * kHistRep + c];
+      if (n) atomicAdd(&p.hist3[(size_t)frame * 768 + i], n);
+    }
     return;
   }
   __shared__ unsigned sh[8][kBlock / 64];
@@ -228,7 +239,7 @@ __device__ __forceinline__ void grayworld_add_swar(const Planar& v, unsigned thr
 // over from one row pair to the next.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, int col_waves, int pairs_per_task, int n_tasks) {
-  __shared__ unsigned s_hist[MODE == WB_SIMPLE ? 768 : 1];
+  __shared__ unsigned s_hist[MODE == WB_SIMPLE ? kHistWordsLds : 1];
   p.mode = MODE;  // the per-pixel switch in stat_add folds away
   stat_hist_init(p, s_hist);
   const int frame = blockIdx.y;
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, int c
 
 // colour input (bgr8 / rgb8), 4 px per lane
 __global__ __launch_bounds__(kBlock) void stats_color_kernel(StatsParams p, ItemMap im, int items_per_frame) {
-  __shared__ unsigned s_hist[768];
+  extern __shared__ unsigned s_hist[];  // kHistWordsLds words for SimpleWB, one otherwise (stats_hist_lds_bytes)
   stat_hist_init(p, s_hist);
   const int frame = blockIdx.y;
   const uint8_t* src = p.src + (size_t)frame * p.src_frame_stride;
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void stats_color_kernel(StatsParams p, Item
 }
 
 __global__ __launch_bounds__(kBlock) void stats_generic_kernel(StatsParams p) {
-  __shared__ unsigned s_hist[768];
+  extern __shared__ unsigned s_hist[];  // kHistWordsLds words for SimpleWB, one otherwise (stats_hist_lds_bytes)
   stat_hist_init(p, s_hist);
   const int frame = blockIdx.y;
   SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
@@ -509,6 +520,8 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
 
 }  // namespace
 
+static unsigned stats_hist_lds_bytes(int mode) { return (mode == WB_SIMPLE ? (unsigned)kHistWordsLds : 1u) * (unsigned)sizeof(unsigned); }
+
 void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream) {
   if (p.n_frames <= 0) return;
   if (bayer_fast_geometry(p.src, p.src_step, p.src_frame_stride, p.rows, p.cols, p.src_kind)) {
@@ -543,12 +556,12 @@ void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream) 
     const int items = p.rows * (p.cols / 4);
     int per_frame = grid_blocks_for(items, std::max(8, 2048 / std::max(1, std::min(p.n_frames, 16))));
     per_frame = std::max(per_frame, (int)((items + (1 << 20) - 1) >> 20));
-    hipLaunchKernelGGL(stats_color_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), 0, stream, p, im, items);
+    hipLaunchKernelGGL(stats_color_kernel, dim3(per_frame, p.n_frames), dim3(kBlock), stats_hist_lds_bytes(p.mode), stream, p, im, items);
     return;
   }
   long long npix = (long long)p.rows * p.cols;
   int blocks = std::max(grid_blocks_for(npix, 1024), (int)((npix + (1 << 22) - 1) >> 22));
-  hipLaunchKernelGGL(stats_generic_kernel, dim3(blocks, p.n_frames), dim3(kBlock), 0, stream, p);
+  hipLaunchKernelGGL(stats_generic_kernel, dim3(blocks, p.n_frames), dim3(kBlock), stats_hist_lds_bytes(p.mode), stream, p);
 }
 
 void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
