@@ -437,11 +437,11 @@ __global__ __launch_bounds__(kBlock) void chain_mono_kernel(ChainParams p, ItemM
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bayer input with a 90 / 270 degree flip (flip.cpp:45-60: transpose + flip == cv::rotate).  Same
-// window / SWAR demosaic / per-pixel stages as chain_fast_kernel, stage set decided at run time.  A
-// 4x2 item lands as four 2-pixel (6-byte) pieces in four output rows, so the lanes of a workgroup are
-// laid out 4 column groups x 64 row pairs: for one output row the 16 row pairs a wave holds write 96
-// contiguous bytes (and the four waves of the workgroup 384), while each source row is still read in
+// Bayer input with a 90 / 270 degree flip (flip.cpp:45-60: transpose + flip == cv::rotate).  Same window, v_lerp_u8
+// demosaic and compile-time stage sets (FastTabs, pointwise4) as chain_fast_kernel -- round 4; until then this kernel
+// carried the round-1 per-pixel stage functions and ran 1.65 x slower than the unrotated chain.  A 4x2 item lands as four
+// 2-pixel (6-byte) pieces in four output rows, so the lanes of a workgroup are laid out 4 column groups x NT / 4 row pairs:
+// for one output row the 16 row pairs a wave holds write 96 contiguous bytes, while each source row is still read in
 // 16..24-byte runs.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void store6(__amdgpu_buffer_rsrc_t frame, unsigned off, uint32_t first, uint32_t second) {
@@ -451,23 +451,27 @@ __device__ __forceinline__ void store6(__amdgpu_buffer_rsrc_t frame, unsigned of
   __builtin_amdgcn_raw_buffer_store_b16((short)(lo >> 16), frame, (int)off + 2, 0, 0);
   __builtin_amdgcn_raw_buffer_store_b16((short)(hi & 0xffffu), frame, (int)off + 4, 0, 0);
 }
+// the four pixels of twelve interleaved bytes as b | g << 8 | r << 16 each
+__device__ __forceinline__ void unpack3(const Pack3& v, uint32_t (&px)[4]) {
+  px[0] = v.a & 0xFFFFFFu;
+  px[1] = (v.a >> 24) | ((v.b & 0xFFFFu) << 8);
+  px[2] = (v.b >> 16) | ((v.c & 0xFFu) << 16);
+  px[3] = v.c >> 8;
+}
 
-__global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int tiles_x, int tiles_per_frame) {
-  __shared__ LdsTabs<ST_CC | ST_GAMMA | ST_VIG | ST_HSV> tb;
-  __shared__ uint8_t s_gamma[256];  // LdsTabs<...VIG> folds gamma into lin_tab; the plain LUT is needed too
-  __shared__ float s_fwd[9];
-  __shared__ int s_inv[6];
-  tb.load(p.tabs);
-  s_gamma[threadIdx.x] = p.tabs->gamma_lut[threadIdx.x];
-  if (threadIdx.x < 9) {
-    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
-    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
-  }
+template <int BITS, int WB, int NT>
+__global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_rot_kernel(ChainParams p, int tiles_x, int tiles_per_frame) {
+  __shared__ FastTabs<BITS> tb;
+  tb.template load<NT>(p.tabs, p.vig_image);
+  CcRegs cc = {};
+  if constexpr ((BITS & ST_CC) != 0) cc.load(p);
+  HsvRegs hr = {};
+  if constexpr ((BITS & ST_HSV) != 0) hr.load(p);
   __syncthreads();
+  constexpr int kPairsPerTile = NT / 4;
   const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
   const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
   const bool rot90 = p.flip_angle == 90;
-  const bool vig = (p.stage_bits & ST_VIG) != 0, gam = (p.stage_bits & ST_GAMMA) != 0;
   const int groups = p.cols >> 2, pairs = p.rows >> 1;
   const unsigned src_bytes = __umul24((unsigned)(p.rows - 1), (unsigned)p.src_step) + (unsigned)p.cols;
   const unsigned dst_bytes = __umul24((unsigned)(p.drows - 1), (unsigned)p.dst_step) + (unsigned)p.dcols * 3u;
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int ti
   const bool has_tap = p.tap != nullptr;
   for (int tile = blockIdx.x; tile < tiles_per_frame; tile += gridDim.x) {
     const int tpy = tile / tiles_x, tgx = tile - tpy * tiles_x;
-    const int grp = tgx * 4 + (int)(threadIdx.x & 3u), pair = tpy * 64 + (int)(threadIdx.x >> 2);
+    const int grp = tgx * 4 + (int)(threadIdx.x & 3u), pair = tpy * kPairsPerTile + (int)(threadIdx.x >> 2);
     if (grp >= groups || pair >= pairs) continue;
     const int y0 = pair * 2, x0 = grp * 4;
     // source (ys, xs) -> 90: (xs, R-1-ys);  270: (C-1-xs, ys)   [oracle/rip_oracle.c ripo_flip]
@@ -488,7 +492,12 @@ __global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int ti
       dst_off[k] = __umul24((unsigned)row_d, (unsigned)p.dst_step) + (unsigned)col_d * 3u;
       tap_off[k] = (__umul24((unsigned)row_d, (unsigned)p.dcols) + (unsigned)col_d) * 3u;
 #pragma unroll
-      for (int ly = 0; ly < 2; ly++) mask[ly][k] = vig ? p.vig_mask[(size_t)row_d * p.dcols + (rot90 ? col_d + 1 - ly : col_d + ly)] : 1.0f;
+      for (int ly = 0; ly < 2; ly++) {
+        if constexpr ((BITS & ST_VIG) != 0)
+          mask[ly][k] = p.vig_mask[(size_t)row_d * p.dcols + (rot90 ? col_d + 1 - ly : col_d + ly)];
+        else
+          mask[ly][k] = 1.0f;
+      }
     }
     const WindowOffsets wo = window_offsets((unsigned)p.src_step, p.rows, p.cols, y0, x0);
     for (int frame = f_begin; frame < f_end; frame++) {
@@ -496,31 +505,46 @@ __global__ __launch_bounds__(kBlock) void chain_rot_kernel(ChainParams p, int ti
       const __amdgpu_buffer_rsrc_t dst = frame_rsrc(p.dst + (size_t)frame * p.dst_frame_stride, dst_bytes);
       const __amdgpu_buffer_rsrc_t tap = frame_rsrc(has_tap ? p.tap + (size_t)frame * p.tap_frame_stride : nullptr, has_tap ? tap_bytes : 0u);
       FrameWb w;
-      if (p.wb_mode != WB_NONE) w = p.wb[frame];
+      if (WB != WB_NONE) w = p.wb[frame];
+      if constexpr (WB == WB_FLOAT || WB == WB_SIMPLE || WB == WB_PCA) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) asm volatile("" : "+v"(w.fg[c]));
+#pragma unroll
+        for (int c = 0; c < 4; c++) asm volatile("" : "+v"(w.pca[c]));
+      }
       Window win;
       load_window(src, wo, win);
       Planar rowpx[2];
       debayer_tile_any(win, p.bayer_ry, p.bayer_rx, y0, x0, p.rows, p.cols, rowpx);
       uint32_t raw[2][4], pix[2][4];  // b | g << 8 | r << 16
 #pragma unroll
-      for (int ly = 0; ly < 2; ly++)
+      for (int ly = 0; ly < 2; ly++) {
+        Planar v = rowpx[ly];
+        Pack3 rawp;
+        const bool need_raw = has_tap || (BITS == 0 && WB == WB_NONE);
+        if (need_raw) {
+          interleave4(v, rawp.a, rawp.b, rawp.c);
+          unpack3(rawp, raw[ly]);
+        }
+        if (BITS == 0 && WB == WB_NONE) {  // pure demosaic: no per-pixel stage
+#pragma unroll
+          for (int k = 0; k < 4; k++) pix[ly][k] = raw[ly][k];
+          continue;
+        }
+        if (WB == WB_Q8) {  // grey-world gains on the packed bytes, two pixels per multiply
+          v.b = gains_q8_swar(v.b, (unsigned)w.q8[0]);
+          v.g = gains_q8_swar(v.g, (unsigned)w.q8[1]);
+          v.r = gains_q8_swar(v.r, (unsigned)w.q8[2]);
+        }
+        int q[4][3];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          int b = (int)((rowpx[ly].b >> (8 * k)) & 0xFFu), g = (int)((rowpx[ly].g >> (8 * k)) & 0xFFu),
-              r = (int)((rowpx[ly].r >> (8 * k)) & 0xFFu);
-          raw[ly][k] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
-          apply_wb(p.wb_mode, w, b, g, r);
-          if (p.stage_bits & ST_CC) apply_cc(p, b, g, r);
-          if (vig) {
-            apply_vignette(p, tb, s_fwd, s_inv, mask[ly][k], b, g, r);
-          } else if (gam) {
-            b = s_gamma[b];
-            g = s_gamma[g];
-            r = s_gamma[r];
-          }
-          if (p.stage_bits & ST_HSV) apply_hsv(p.hsv_gain, tb, b, g, r);
-          pix[ly][k] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+          q[k][0] = (int)((v.b >> (8 * k)) & 0xFFu);
+          q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
+          q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
         }
+        unpack3(pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(p, w, tb, cc, hr, mask[ly], q), pix[ly]);
+      }
       const int first = rot90 ? 1 : 0;  // which source row lands in the left destination column
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -553,6 +577,22 @@ void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, 
                  fa.numRegs, fa.sharedSizeBytes, grid.x, grid.y);
   }
   hipLaunchKernelGGL((chain_fast_kernel<BITS, WB, NT>), grid, dim3(NT), 0, stream, p, im, items);
+}
+
+template <int BITS, int WB>
+void launch_rot(const ChainParams& p, int tiles_x, int tiles, dim3 grid, hipStream_t stream) {
+  constexpr int NT = fast_threads<BITS>();
+  hipLaunchKernelGGL((chain_rot_kernel<BITS, WB, NT>), grid, dim3(NT), 0, stream, p, tiles_x, tiles);
+}
+template <int BITS>
+void launch_rot_wb(const ChainParams& p, int tiles_x, int tiles, dim3 grid, hipStream_t stream) {
+  switch (p.wb_mode) {
+    case WB_Q8: launch_rot<BITS, WB_Q8>(p, tiles_x, tiles, grid, stream); break;
+    case WB_FLOAT: launch_rot<BITS, WB_FLOAT>(p, tiles_x, tiles, grid, stream); break;
+    case WB_PCA: launch_rot<BITS, WB_PCA>(p, tiles_x, tiles, grid, stream); break;
+    case WB_SIMPLE: launch_rot<BITS, WB_SIMPLE>(p, tiles_x, tiles, grid, stream); break;
+    default: launch_rot<BITS, WB_NONE>(p, tiles_x, tiles, grid, stream); break;
+  }
 }
 
 template <int BITS>
@@ -639,12 +679,19 @@ void launch_debayer16(const Debayer16Params& p, hipStream_t stream) {
 void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream) {
   if (p.n_frames <= 0) return;
   if (chain_uses_rot_path(p)) {
-    const int tiles_x = (p.cols / 4 + 3) / 4, tiles_y = (p.rows / 2 + 63) / 64;
+    const int nt = (p.stage_bits & ST_VIG) ? fast_threads<ST_VIG>() : fast_threads<0>();
+    const int tiles_x = (p.cols / 4 + 3) / 4, tiles_y = (p.rows / 2 + nt / 4 - 1) / (nt / 4);
     const int tiles = tiles_x * tiles_y;
-    const int cap = grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : 2048);
+    const int dflt_blocks = nt == kBlock ? 2048 : 4096;
+    const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : dflt_blocks) * kBlock / nt / 8 * 8);
     const int blocks = std::min(cap, tiles);
-    const int groups = frame_groups(p, tn, cap, blocks);
-    hipLaunchKernelGGL(chain_rot_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, tiles_x, tiles);
+    const dim3 grid(blocks, frame_groups(p, tn, cap, blocks));
+    switch (p.stage_bits & 15) {
+#define RIP_CASE(B) case B: launch_rot_wb<B>(p, tiles_x, tiles, grid, stream); break;
+      RIP_CASE(0) RIP_CASE(1) RIP_CASE(2) RIP_CASE(3) RIP_CASE(4) RIP_CASE(5) RIP_CASE(6) RIP_CASE(7)
+      RIP_CASE(8) RIP_CASE(9) RIP_CASE(10) RIP_CASE(11) RIP_CASE(12) RIP_CASE(13) RIP_CASE(14) RIP_CASE(15)
+#undef RIP_CASE
+    }
     return;
   }
   if (chain_uses_fast_path(p)) {
