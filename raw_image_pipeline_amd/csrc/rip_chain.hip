@@ -321,29 +321,30 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
 
 
 // ------------------------------------------------------------------------------------------------
-// colour-input path (bgr8 / rgb8 frames, e.g. the reference's Python demo): 4 px per lane, 12-byte
-// loads and stores, flip 0/180, stage set decided at run time (wave-uniform branches), all tables in LDS
+// colour-input path (bgr8 / rgb8 frames: the reference's Python demo, and every compressed transport of the ROS node, which
+// cv_bridge converts to bgr8, raw_image_pipeline_ros.cpp:226-231): 4 px per lane, 12-byte loads and stores, flip 0 / 180.
+// Round 4: the compile-time stage sets and tables of chain_fast_kernel (FastTabs, pointwise4) instead of the round-1
+// per-pixel stage functions with run-time stage tests.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, ItemMap im, int items_per_frame) {
-  __shared__ LdsTabs<ST_CC | ST_GAMMA | ST_VIG | ST_HSV> tb;
-  __shared__ uint8_t s_gamma[256];  // LdsTabs<...VIG> folds gamma into lin_tab; the plain LUT is needed too
-  __shared__ float s_fwd[9];
-  __shared__ int s_inv[6];
-  tb.load(p.tabs);
-  s_gamma[threadIdx.x] = p.tabs->gamma_lut[threadIdx.x];
-  if (threadIdx.x < 9) {
-    s_fwd[threadIdx.x] = (float)p.tabs->lab_fwd[threadIdx.x];
-    if (threadIdx.x < 6) s_inv[threadIdx.x] = p.tabs->lab_inv_pk[threadIdx.x];
-  }
+template <int BITS, int WB, int NT>
+__global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_color_kernel(ChainParams p, ItemMap im, int items_per_frame) {
+  __shared__ FastTabs<BITS> tb;
+  tb.template load<NT>(p.tabs, p.vig_image);
+  CcRegs cc = {};
+  if constexpr ((BITS & ST_CC) != 0) cc.load(p);
+  HsvRegs hr = {};
+  if constexpr ((BITS & ST_HSV) != 0) hr.load(p);
   __syncthreads();
-  const int chunks_per_frame = (items_per_frame + kBlock - 1) / kBlock;
+  const int chunks_per_frame = (items_per_frame + NT - 1) / NT;
   const int f_per_group = (p.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
   const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(p.n_frames, f_begin + f_per_group);
   const bool flip180 = p.flip_angle == 180;
   const bool rgb = p.src_kind == SRC_RGB;
-  const bool vig = (p.stage_bits & ST_VIG) != 0, gam = (p.stage_bits & ST_GAMMA) != 0;
+  const bool has_tap = p.tap != nullptr;
+  const bool dst_nt = p.dst_streaming != 0;
+  const unsigned dst_bytes = __umul24((unsigned)(p.drows - 1), (unsigned)p.dst_step) + (unsigned)p.dcols * 3u;
   for (int chunk = blockIdx.x; chunk < chunks_per_frame; chunk += gridDim.x) {
-    const int item = chunk * kBlock + threadIdx.x;
+    const int item = chunk * NT + threadIdx.x;
     if (item >= items_per_frame) continue;
     int ys, grp;
     im.split(item, ys, grp);
@@ -351,40 +352,37 @@ __global__ __launch_bounds__(kBlock) void chain_color_kernel(ChainParams p, Item
     const int yd = flip180 ? p.rows - 1 - ys : ys;
     const int xbase = flip180 ? p.cols - 4 - x0 : x0;
     float mask[4];
+    if constexpr ((BITS & ST_VIG) != 0) {
+      const float4 m = *reinterpret_cast<const float4*>(p.vig_mask + (size_t)yd * p.dcols + xbase);  // dcols % 4 == 0, xbase % 4 == 0
+      mask[0] = m.x;
+      mask[1] = m.y;
+      mask[2] = m.z;
+      mask[3] = m.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) mask[k] = vig ? p.vig_mask[(size_t)yd * p.dcols + xbase + k] : 1.0f;
+      for (int k = 0; k < 4; k++) mask[k] = 1.0f;
+    }
     const unsigned src_off = __umul24((unsigned)ys, (unsigned)p.src_step) + (unsigned)x0 * 3u;
     const unsigned dst_off = __umul24((unsigned)yd, (unsigned)p.dst_step) + (unsigned)xbase * 3u;
     const unsigned tap_off = (__umul24((unsigned)yd, (unsigned)p.dcols) + (unsigned)xbase) * 3u;
     for (int frame = f_begin; frame < f_end; frame++) {
       const uint3 in = *reinterpret_cast<const uint3*>(p.src + (size_t)frame * p.src_frame_stride + src_off);
       FrameWb w;
-      if (p.wb_mode != WB_NONE) w = p.wb[frame];
+      if (WB != WB_NONE) w = p.wb[frame];
+      if constexpr (WB == WB_FLOAT || WB == WB_SIMPLE || WB == WB_PCA) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) asm volatile("" : "+v"(w.fg[c]));
+#pragma unroll
+        for (int c = 0; c < 4; c++) asm volatile("" : "+v"(w.pca[c]));
+      }
       int s[4][3], q[4][3];
       unpack12(in, rgb, s);
 #pragma unroll
       for (int k = 0; k < 4; k++)
 #pragma unroll
         for (int c = 0; c < 3; c++) q[k][c] = flip180 ? s[3 - k][c] : s[k][c];
-      if (p.tap) store12(p.tap + (size_t)frame * p.tap_frame_stride + tap_off, pack4(q));
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int b = q[k][0], g = q[k][1], r = q[k][2];
-        apply_wb(p.wb_mode, w, b, g, r);
-        if (p.stage_bits & ST_CC) apply_cc(p, b, g, r);
-        if (vig) {
-          apply_vignette(p, tb, s_fwd, s_inv, mask[k], b, g, r);
-        } else if (gam) {
-          b = s_gamma[b];
-          g = s_gamma[g];
-          r = s_gamma[r];
-        }
-        if (p.stage_bits & ST_HSV) apply_hsv(p.hsv_gain, tb, b, g, r);
-        q[k][0] = b;
-        q[k][1] = g;
-        q[k][2] = r;
-      }
-      store12(p.dst + (size_t)frame * p.dst_frame_stride + dst_off, pack4(q));
+      if (has_tap) store12(p.tap + (size_t)frame * p.tap_frame_stride + tap_off, pack4(q));
+      store12(frame_rsrc(p.dst + (size_t)frame * p.dst_frame_stride, dst_bytes), dst_off, pointwise4<BITS, WB>(p, w, tb, cc, hr, mask, q), dst_nt);
     }
   }
 }
@@ -580,6 +578,22 @@ void launch_fast(const ChainParams& p, const ItemMap& im, int items, dim3 grid, 
 }
 
 template <int BITS, int WB>
+void launch_color(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
+  constexpr int NT = fast_threads<BITS>();
+  hipLaunchKernelGGL((chain_color_kernel<BITS, WB, NT>), grid, dim3(NT), 0, stream, p, im, items);
+}
+template <int BITS>
+void launch_color_wb(const ChainParams& p, const ItemMap& im, int items, dim3 grid, hipStream_t stream) {
+  switch (p.wb_mode) {
+    case WB_Q8: launch_color<BITS, WB_Q8>(p, im, items, grid, stream); break;
+    case WB_FLOAT: launch_color<BITS, WB_FLOAT>(p, im, items, grid, stream); break;
+    case WB_PCA: launch_color<BITS, WB_PCA>(p, im, items, grid, stream); break;
+    case WB_SIMPLE: launch_color<BITS, WB_SIMPLE>(p, im, items, grid, stream); break;
+    default: launch_color<BITS, WB_NONE>(p, im, items, grid, stream); break;
+  }
+}
+
+template <int BITS, int WB>
 void launch_rot(const ChainParams& p, int tiles_x, int tiles, dim3 grid, hipStream_t stream) {
   constexpr int NT = fast_threads<BITS>();
   hipLaunchKernelGGL((chain_rot_kernel<BITS, WB, NT>), grid, dim3(NT), 0, stream, p, tiles_x, tiles);
@@ -719,10 +733,18 @@ void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream) 
   if (chain_uses_color_path(p)) {
     ItemMap im{p.cols / 4, 1.0f / (float)(p.cols / 4)};
     const int items = p.rows * (p.cols / 4);
-    const int chunks = (items + kBlock - 1) / kBlock;
-    const int blocks = std::min(2048, chunks);
-    const int groups = frame_groups(p, tn, 2048, blocks);
-    hipLaunchKernelGGL(chain_color_kernel, dim3(blocks, groups), dim3(kBlock), 0, stream, p, im, items);
+    const int nt = (p.stage_bits & ST_VIG) ? fast_threads<ST_VIG>() : fast_threads<0>();
+    const int chunks = (items + nt - 1) / nt;
+    const int dflt_blocks = nt == kBlock ? 2048 : 4096;
+    const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : dflt_blocks) * kBlock / nt / 8 * 8);
+    const int blocks = std::min(cap, chunks);
+    const dim3 grid(blocks, frame_groups(p, tn, cap, blocks));
+    switch (p.stage_bits & 15) {
+#define RIP_CASE(B) case B: launch_color_wb<B>(p, im, items, grid, stream); break;
+      RIP_CASE(0) RIP_CASE(1) RIP_CASE(2) RIP_CASE(3) RIP_CASE(4) RIP_CASE(5) RIP_CASE(6) RIP_CASE(7)
+      RIP_CASE(8) RIP_CASE(9) RIP_CASE(10) RIP_CASE(11) RIP_CASE(12) RIP_CASE(13) RIP_CASE(14) RIP_CASE(15)
+#undef RIP_CASE
+    }
     return;
   }
   if (chain_uses_mono_path(p)) {

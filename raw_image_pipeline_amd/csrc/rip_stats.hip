@@ -323,6 +323,20 @@ __global__ __launch_bounds__(kBlock) void stats_color_kernel(StatsParams p, Item
     int y, grp;
     im.split(item, y, grp);
     const uint3 in = *reinterpret_cast<const uint3*>(src + (__umul24((unsigned)y, (unsigned)p.src_step) + (unsigned)grp * 12u));
+    if (p.mode == WB_Q8) {  // uniform: the grey-world keep test and masked sums on packed planes, as for Bayer frames
+      // bytes 0 3 6 9 / 1 4 7 10 / 2 5 8 11 of the twelve (hipcc turns the masks and shifts into byte permutes)
+      Planar v;
+      v.b = (in.x & 0xFFu) | ((in.x >> 16) & 0xFF00u) | ((in.y & 0x00FF0000u)) | ((in.z & 0x0000FF00u) << 16);
+      v.g = ((in.x >> 8) & 0xFFu) | ((in.y & 0xFFu) << 8) | ((in.y >> 8) & 0x00FF0000u) | ((in.z & 0x00FF0000u) << 8);
+      v.r = ((in.x >> 16) & 0xFFu) | (in.y & 0xFF00u) | ((in.z & 0xFFu) << 16) | (in.z & 0xFF000000u);
+      if (rgb) {  // cvtColor(RGB2BGR), debayer.cpp:72-73
+        const uint32_t t = v.b;
+        v.b = v.r;
+        v.r = t;
+      }
+      grayworld_add_swar(v, min(p.thresh255, 255u), a);
+      continue;
+    }
     int q[4][3];
     unpack12(in, rgb, q);
 #pragma unroll
