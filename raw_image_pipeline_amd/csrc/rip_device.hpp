@@ -165,49 +165,6 @@ struct LdsArr<false, T, N> {
   T v[1];
 };
 
-template <int BITS>
-struct LdsTabs {
-  static constexpr bool kVig = (BITS & ST_VIG) != 0;
-  static constexpr bool kHsv = (BITS & ST_HSV) != 0;
-  // gamma bytes are only needed when the gamma result itself is consumed (not folded into lin_tab)
-  static constexpr bool kGamma = (BITS & ST_GAMMA) != 0 && !kVig;
-  LdsArr<kGamma, uint8_t, 256> gamma_;
-  LdsArr<kVig, float, 256> lin_;    // exact small integers held as float: the Lab forward sums run
-  LdsArr<kVig, float, 3072> cbrt_;  // on v_fma_f32 (2 cycles) instead of v_mad_i32_i24 (4 cycles)
-  LdsArr<kVig, uint32_t, 256> yf_;
-  LdsArr<kVig, uint8_t, 4096> invg_;
-  LdsArr<kHsv, int32_t, 256> sdiv_;
-  LdsArr<kHsv, int32_t, 256> hdiv_;
-  __device__ __forceinline__ int gamma(int i) const { return gamma_.v[i]; }
-  __device__ __forceinline__ float linf(int i) const { return lin_.v[i]; }
-  __device__ __forceinline__ float cbrtf(unsigned i) const { return cbrt_.v[i]; }
-  __device__ __forceinline__ unsigned yf(int i) const { return yf_.v[i]; }
-  __device__ __forceinline__ int invg(int i) const { return invg_.v[i]; }
-  __device__ __forceinline__ int sdiv(int i) const { return sdiv_.v[i]; }
-  __device__ __forceinline__ int hdiv(int i) const { return hdiv_.v[i]; }
-
-  template <typename T, int N>
-  static __device__ __forceinline__ void copy(T (&dst)[N], const T* src) {
-    static_assert((N * sizeof(T)) % 4 == 0, "table size");
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
-    for (int i = threadIdx.x; i < (int)(N * sizeof(T) / 4); i += kBlock) d[i] = s[i];
-  }
-  __device__ __forceinline__ void load(const DevTables* t) {
-    if constexpr (kGamma) copy(gamma_.v, t->gamma_lut);
-    if constexpr (kVig) {
-      for (int i = threadIdx.x; i < 256; i += kBlock) lin_.v[i] = (float)t->lin_tab[i];
-      for (int i = threadIdx.x; i < 3072; i += kBlock) cbrt_.v[i] = (float)t->cbrt_tab[i];
-      copy(yf_.v, t->yf_tab);
-      copy(invg_.v, t->inv_gamma);
-    }
-    if constexpr (kHsv) {
-      copy(sdiv_.v, t->sdiv);
-      copy(hdiv_.v, t->hdiv);
-    }
-  }
-};
-
 // ------------------------------------------------------------------------------------------------
 // per-pixel stages
 // ------------------------------------------------------------------------------------------------
