@@ -255,6 +255,8 @@ class RawImagePipeline {
   // the taps travel with the result into the handle's pinned host memory (rip_get_image_view), so a publisher that serialises
   // the image at once needs no second device read and no memcpy.  Valid until the next collect*() on this object; frames of
   // apply() / process() only exist on the device and come back as a copy, like the getters above.
+  // setTapDownload(RIP_TAP_DEBAYERED | RIP_TAP_COLOR) makes submit() download those taps with the result (default: none).
+  void setTapDownload(int mask) { check(rip_set_tap_download(h_, mask)); }
   Mat getDistDebayeredImageView() const { return image_view(RIP_IMAGE_DEBAYERED); }
   Mat getDistColorImageView() const { return image_view(RIP_IMAGE_COLOR); }
   Mat getProcessedImageView() const { return image_view(RIP_IMAGE_PROCESSED); }

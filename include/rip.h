@@ -135,12 +135,18 @@ void rip_host_free(void* ptr);
  * rect_mask_ (undistortion.cpp:150-152). */
 rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_capacity, int* rows, int* cols,
                          int* channels);
-/* The same image without a copy, for frames that came through rip_collect: the taps the mask keeps are downloaded
- * together with the result, so after rip_collect *view points into the handle's pinned host memory (valid as long as the
+/* The same image without a copy, for frames that came through rip_collect: the final image always, the taps named by
+ * rip_set_tap_download are downloaded together with the result, so after rip_collect *view points into the handle's pinned host memory (valid as long as the
  * rip_collect view: until the next rip_collect on the handle or until a rip_submit takes the slot).  *view is NULL -- with
  * the geometry still reported -- when the image only exists on the device (frames of rip_apply): use rip_get_image then.
  * hpp:134-137 (getDistDebayeredImage / getDistColorImage / getProcessedImage return Mat headers, no copy either). */
 rip_status rip_get_image_view(rip_pipeline* p, int which, const uint8_t** view, int* rows, int* cols, int* channels);
+/* Which of the kept taps (RIP_TAP_DEBAYERED | RIP_TAP_COLOR) rip_submit ALSO downloads into pinned host memory together
+ * with the result, for rip_get_image_view / a copy-free rip_get_image after rip_collect.  Default 0: the taps stay on the
+ * device until a getter asks (one synchronous device read each), and a caller that only wants the final image moves no
+ * extra bytes.  A front end that publishes the taps of every frame (raw_image_pipeline_ros.cpp:245-287) sets the bits of
+ * the images it publishes. */
+rip_status rip_set_tap_download(rip_pipeline* p, int tap_mask);
 /* Which taps rip_apply materialises (default: all three, as the reference does). */
 rip_status rip_set_taps(rip_pipeline* p, int tap_mask);
 

@@ -133,7 +133,8 @@ struct RingSlot {
   bool busy = false;  // submitted, not collected yet
   bool held = false;  // collected: the pinned result and the taps stay put until the next collect (or until a submit needs the slot)
   Plan pl;
-  bool has_deb = false, has_col = false;
+  bool has_deb = false, has_col = false;  // the taps this frame keeps on the device
+  bool dl_deb = false, dl_col = false;    // ... and downloads into h_tap with the result
   void reserve_host(size_t bytes) {
     if (bytes <= h_out_cap) return;
     if (h_out) HIP_CHECK(hipHostFree(h_out));
@@ -185,6 +186,7 @@ struct rip_pipeline {
   std::string ccc_model_env;      // RIP_CCC_MODEL
   mutable std::string last_error;
   int tap_mask = RIP_TAP_DEBAYERED | RIP_TAP_COLOR | RIP_TAP_PROCESSED;
+  int tap_download_mask = 0;  // rip_set_tap_download: which of the kept taps rip_submit also downloads with the result
 
   // constants on the device
   rip::DevTables h_tabs;
@@ -1331,14 +1333,12 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     sl.reserve_host(out_bytes);
     sl.has_deb = (p->tap_mask & RIP_TAP_DEBAYERED) && eb == 1;
     sl.has_col = (p->tap_mask & RIP_TAP_COLOR) && eb == 1;
-    if (sl.has_deb) {
-      sl.d_tap_deb.reserve(mid_bytes);
-      RingSlot::reserve_pinned(sl.h_tap[0], sl.h_tap_cap[0], mid_bytes);
-    }
-    if (sl.has_col) {
-      sl.d_tap_col.reserve(mid_bytes);
-      RingSlot::reserve_pinned(sl.h_tap[1], sl.h_tap_cap[1], mid_bytes);
-    }
+    sl.dl_deb = sl.has_deb && (p->tap_download_mask & RIP_TAP_DEBAYERED);
+    sl.dl_col = sl.has_col && (p->tap_download_mask & RIP_TAP_COLOR);
+    if (sl.has_deb) sl.d_tap_deb.reserve(mid_bytes);
+    if (sl.has_col) sl.d_tap_col.reserve(mid_bytes);
+    if (sl.dl_deb) RingSlot::reserve_pinned(sl.h_tap[0], sl.h_tap_cap[0], mid_bytes);
+    if (sl.dl_col) RingSlot::reserve_pinned(sl.h_tap[1], sl.h_tap_cap[1], mid_bytes);
     // upload (its own stream: it overlaps the kernels of the frame before) -> kernels on the handle's stream, in submission
     // order -> download into the slot's pinned buffer (its own stream: it overlaps the kernels of the frame after)
     // A frame in pinned memory (rip_host_alloc, hipHostMalloc, hipHostRegister) is DMA'd from where it lies and must stay
@@ -1365,11 +1365,12 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     HIP_CHECK(hipEventRecord(sl.ev_kernels, p->stream));
     HIP_CHECK(hipStreamWaitEvent(p->dl_stream, sl.ev_kernels, 0));
     HIP_CHECK(hipMemcpyAsync(sl.h_out, sl.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, p->dl_stream));
-    // the taps the mask keeps travel with the result: a per-frame caller that publishes them (raw_image_pipeline_ros.cpp:
-    // 245-287: up to three images per callback) gets them from pinned host memory instead of one synchronous device read
-    // each (rip_get_image / rip_get_image_view after rip_collect)
-    if (sl.has_deb) HIP_CHECK(hipMemcpyAsync(sl.h_tap[0], sl.d_tap_deb.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
-    if (sl.has_col) HIP_CHECK(hipMemcpyAsync(sl.h_tap[1], sl.d_tap_col.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
+    // the taps rip_set_tap_download names travel with the result: a per-frame caller that publishes them
+    // (raw_image_pipeline_ros.cpp:245-287: up to three images per callback) gets them from pinned host memory instead of
+    // one synchronous device read each (rip_get_image / rip_get_image_view after rip_collect).  Off by default: a caller that
+    // only wants the final image must not pay 30 MB more PCIe traffic per 2448 x 2048 frame.
+    if (sl.dl_deb) HIP_CHECK(hipMemcpyAsync(sl.h_tap[0], sl.d_tap_deb.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
+    if (sl.dl_col) HIP_CHECK(hipMemcpyAsync(sl.h_tap[1], sl.d_tap_col.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
     HIP_CHECK(hipEventRecord(sl.ev_done, p->dl_stream));
     sl.pl = pl;
     sl.ticket = p->next_ticket++;
@@ -1405,8 +1406,8 @@ rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t ou
       p->last_cols[which] = c;
       p->last_cn[which] = pl.channels;
     };
-    remember(RIP_IMAGE_DEBAYERED, &sl->d_tap_deb, sl->h_tap[0], pl.mid_rows, pl.mid_cols, sl->has_deb);
-    remember(RIP_IMAGE_COLOR, &sl->d_tap_col, sl->h_tap[1], pl.mid_rows, pl.mid_cols, sl->has_col);
+    remember(RIP_IMAGE_DEBAYERED, &sl->d_tap_deb, sl->dl_deb ? sl->h_tap[0] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_deb);
+    remember(RIP_IMAGE_COLOR, &sl->d_tap_col, sl->dl_col ? sl->h_tap[1] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_col);
     remember(RIP_IMAGE_PROCESSED, &sl->d_out, sl->h_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0 && eb1);
     if (out_rows) *out_rows = pl.out_rows;
     if (out_cols) *out_cols = pl.out_cols;
@@ -1493,6 +1494,13 @@ rip_status rip_set_taps(rip_pipeline* p, int mask) {
   return guarded(p, [&] {
     need(p);
     p->tap_mask = mask & 7;
+  });
+}
+
+rip_status rip_set_tap_download(rip_pipeline* p, int mask) {
+  return guarded(p, [&] {
+    need(p);
+    p->tap_download_mask = mask & (RIP_TAP_DEBAYERED | RIP_TAP_COLOR);
   });
 }
 

@@ -306,9 +306,23 @@ __global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
   __syncthreads();
   const int frame = blockIdx.y;
   SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < 360 * 270; i += kHistBlocks * kBlock) {
-    const int bin = ccc_sample_bin(p, tb, s, i);
-    if (bin >= 0) atomicAdd(&p.hist_counts[(size_t)frame * 65536 + bin], 1u);
+  // two samples per thread and trip through the straight-line sampler (window loads of both in flight together, packed
+  // demosaic; unflipped and 180-degree frames), like the LDS-histogram kernel below
+  constexpr int kUnroll = 2;
+  const bool frame_straight = ccc_frame_straight(p, s);
+  for (int i0 = blockIdx.x * kBlock + threadIdx.x; i0 < 360 * 270; i0 += kUnroll * kHistBlocks * kBlock) {
+    int bin[kUnroll], idx[kUnroll];
+    bool live[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+      const int i = i0 + k * kHistBlocks * kBlock;
+      live[k] = i < 360 * 270;
+      idx[k] = live[k] ? i : 360 * 270 - 1;
+    }
+    ccc_sample_bins<kUnroll>(p, tb, s, frame_straight, idx, live, bin);
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++)
+      if (bin[k] >= 0) atomicAdd(&p.hist_counts[(size_t)frame * 65536 + bin[k]], 1u);
   }
 }
 

@@ -141,6 +141,7 @@ class CameraStream:
             mask |= TAP_COLOR
         if mask != getattr(self, "_tap_mask", None):
             self.pipe.set_taps(mask)
+            self.pipe.set_tap_download(mask)  # every kept tap is published: let it travel with the result of a submit()
             self._tap_mask = mask
 
     def on_image(self, image, encoding, stamp=0.0, frame_id="camera"):

@@ -276,6 +276,11 @@ class RawImagePipeline:
     def set_taps(self, mask):
         self._call("rip_set_taps", int(mask))
 
+    def set_tap_download(self, mask):
+        """Which of the kept taps (TAP_DEBAYERED | TAP_COLOR) ``submit`` downloads into pinned memory with the result
+        (rip_set_tap_download; default none): what a front end that publishes them on every frame wants."""
+        self._call("rip_set_tap_download", int(mask))
+
     def _get_image(self, which, copy=True):
         """``copy=False``: for a frame that came through ``collect`` a read-only view of the handle's pinned host memory
         (rip_get_image_view; same lifetime as ``collect(copy=False)``); frames of ``process`` only exist on the device and are

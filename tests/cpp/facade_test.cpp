@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
   if (std::memcmp(fin.data, out.data, (size_t)w * h * 3) != 0) return fail("processed tap");
   // streaming extension: submit() / collect(): two frames in flight, a view of the pinned result and a copy
   {
+    proc.setTapDownload(RIP_TAP_DEBAYERED | RIP_TAP_COLOR);  // the taps travel with the result of the frames below
     const uint64_t t1 = proc.submit(bayer, "bayer_rggb8"), t2 = proc.submit(bayer, "bayer_rggb8");
     std::string e1, e2;
     Mat v1 = proc.collectView(t1, e1);

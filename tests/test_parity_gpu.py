@@ -746,6 +746,12 @@ def test_submit_reads_a_pageable_5_MB_frame_before_it_returns(rip_lib):
         want_deb.append(pipe.get_dist_debayered_image())
         want_col.append(pipe.get_dist_color_image())
     assert not np.array_equal(want[0], want[1])
+    # without rip_set_tap_download the taps of a collected frame stay on the device: the view getter falls back to a copy
+    t = pipe.submit(frames[0], "bayer_rggb8")
+    assert_images_equal(pipe.collect(t), want[0], "submit without tap download")
+    assert pipe.get_dist_color_image(copy=False).flags.writeable  # a fresh copy, not a view of pinned memory
+    assert_images_equal(pipe.get_dist_color_image(copy=False), want_col[0], "tap read from the device after collect")
+    pipe.set_tap_download(3)  # TAP_DEBAYERED | TAP_COLOR: from here on they travel with the result
     buf = np.empty((h, w), np.uint8)
     tickets = []
     for i, f in enumerate(frames):
