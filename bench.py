@@ -46,9 +46,14 @@ BYTES_PER_PX = {
 }
 
 
+FUSED = {"on": False}  # set by main(): no chain launch was recorded although the workload has a chain -> rip_fused.hip ran
+
+
 def bytes_per_px(kernel_class, frames_per_launch):
     if kernel_class == "remap":
-        return 6.0 + 4.0 / max(frames_per_launch, 1)
+        # two kernels: 3 B gathered + 3 B written (+ plan).  Chain inside the remap's tiles (memory-rate stage sets, no tap:
+        # csrc/rip_fused.hip): 1 B of Bayer read + 3 B written (+ plan) -- there is no intermediate image
+        return (4.0 if FUSED["on"] else 6.0) + 4.0 / max(frames_per_launch, 1)
     return BYTES_PER_PX[kernel_class]
 
 
@@ -432,6 +437,7 @@ def main():
     fps = total_frames / elapsed
 
     # roofline of the dominant kernel class, from the HIP events recorded around its launches
+    FUSED["on"] = prof.get("remap", (0, 0))[1] > 0 and prof.get("chain", (0, 0))[1] == 0
     px = width * height
     # the streaming class with the largest total; the ccc estimator (O(1) bytes per frame) is listed in
     # kernel_ms_per_step but has no HBM roofline
@@ -606,7 +612,8 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%dx%d %s, %s" % (width, height, pattern, stages), "frames_per_step_per_gpu": args.batch,
-                   "sharding": "one camera stream per GPU, no data-path collective", "name": args.workload},
+                   "sharding": "one camera stream per GPU, no data-path collective", "name": args.workload,
+                   "chain_inside_remap_tiles": FUSED["on"]},
         "roofline": roofline,
     }
     if scatter is not None:

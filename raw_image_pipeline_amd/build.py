@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librip_hip.so")
-SOURCES = ["rip_chain.hip", "rip_stats.hip", "rip_ccc.hip", "rip_remap.hip", "rip_maps.hip", "rip_probe.hip", "rip_host.cpp", "rip_api.cpp"]  # compiled in parallel
-HEADERS = ["rip_kernels.hpp", "rip_device.hpp", "rip_tile.hpp", "rip_host.hpp", os.path.join("..", "..", "include", "rip.h")]
+SOURCES = ["rip_chain.hip", "rip_stats.hip", "rip_ccc.hip", "rip_remap.hip", "rip_maps.hip", "rip_fused.hip", "rip_probe.hip", "rip_host.cpp", "rip_api.cpp"]  # compiled in parallel
+HEADERS = ["rip_kernels.hpp", "rip_device.hpp", "rip_chain_dev.hpp", "rip_remap_dev.hpp", "rip_tile.hpp", "rip_host.hpp", os.path.join("..", "..", "include", "rip.h")]
 # per-source additions.  rip_chain.hip: LLVM's max-ILP machine scheduler -- the fused chain is bound by VALU issue and LDS at
 # six waves per SIMD and gains 2.3 % from the extra instruction-level parallelism inside a wave (2.311 -> 2.257 ms per 256
 # frames); the same strategy costs the memory-bound remap 3.5 % and the ccc kernels 8 %, so it is not a global flag.

@@ -709,10 +709,77 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   }
   uint8_t* chain_dst = d_out;
   size_t chain_step = out_step, chain_stride = out_frame_stride;
-  bool tiled = false;
+  bool tiled = false, fused = false;
+  // the remap's view of one group of frames: plan, destination, and -- `src` -- either the intermediate image or, on the
+  // fused path, the Bayer frames themselves
+  auto tiled_params = [&](const uint8_t* src, size_t src_step, size_t src_frame_stride, int src_rows, int src_cols, int f0, int ng) {
+    rip::RemapTiledParams tp = {};
+    rip::RemapParams& r = tp.base;
+    r.src = src;
+    r.src_step = src_step;
+    r.src_frame_stride = src_frame_stride;
+    r.rows = src_rows;
+    r.cols = src_cols;
+    r.channels = pl.channels;
+    r.map_xy = p->d_map.as<float>();
+    r.dst = d_out + (size_t)f0 * out_frame_stride;
+    r.dst_step = out_step;
+    r.dst_frame_stride = out_frame_stride;
+    r.drows = pl.out_rows;
+    r.dcols = pl.out_cols;
+    r.n_frames = ng;
+    tp.words = p->d_plan_words.as<uint32_t>();
+    tp.tiles = p->d_plan_tiles.as<rip::RemapTileDesc>();
+    tp.tiles_x = p->plan.tiles_x;
+    tp.tiles_y = p->plan.tiles_y;
+    tp.border_list = p->d_plan_border.as<uint32_t>();
+    tp.n_border = p->plan_n_border;
+    tp.lds_bytes = (unsigned)p->plan.max_lds_bytes;
+    return tp;
+  };
+  // the chain's parameters for one group of frames (dst / taps filled in by the caller)
+  auto chain_params = [&](const uint8_t* in_g, rip::FrameWb* wb_g, int ng) {
+    rip::ChainParams c = {};
+    c.src = in_g;
+    c.src_step = in_step;
+    c.src_frame_stride = in_frame_stride;
+    c.rows = rows;
+    c.cols = cols;
+    c.src_kind = pl.src_kind;
+    c.bayer_ry = pl.ry;
+    c.bayer_rx = pl.rx;
+    c.drows = pl.mid_rows;
+    c.dcols = pl.mid_cols;
+    c.channels = pl.channels;
+    c.flip_angle = pl.flip_angle;
+    c.n_frames = ng;
+    c.wb_mode = pl.wb_mode;
+    c.wb = wb_g;
+    c.stage_bits = pl.stage_bits;
+    for (int i = 0; i < 9; i++) c.cc_m[i] = p->m.cc_matrix[i];
+    for (int i = 0; i < 3; i++) c.cc_bias[i] = (float)p->m.cc_bias[i];
+    if (pl.stage_bits & rip::ST_VIG) c.vig_mask = p->d_vig.as<float>();
+    // cv::Scalar(hue_gain_, saturation_gain_, value_gain_) on (H,S,V), color_enhancer.cpp:42
+    c.hsv_gain[0] = (float)p->m.ce_hue_gain;
+    c.hsv_gain[1] = (float)p->m.ce_saturation_gain;
+    c.hsv_gain[2] = (float)p->m.ce_value_gain;
+    c.tabs = p->d_tabs.as<rip::DevTables>();
+    c.vig_image = p->d_vig_image.as<uint32_t>();
+    return c;
+  };
   if (pl.remap) {
     ensure_maps(p);
-    if (d_tap_col) {  // the pre-undistortion image is an API output: write it once, gather from it
+    if (p->use_tiled_remap && (pl.channels == 3 || pl.channels == 1)) {
+      ensure_plan(p, pl.mid_rows, pl.mid_cols);
+      tiled = true;
+    }
+    // Memory-rate stage sets with neither tap requested: the remap's tiles demosaic and colour their own source rectangles
+    // out of the Bayer frames (rip_fused.hip) -- no intermediate image is written, read or even allocated.
+    if (tiled && !d_tap_col && !d_tap_deb && pl.src_kind == rip::SRC_BAYER)
+      fused = rip::launch_remap_fused(tiled_params(d_in, in_step, in_frame_stride, rows, cols, 0, n), chain_params(d_in, p->d_wb.as<rip::FrameWb>(), n),
+                                      p->plan.max_rect_w, p->plan.max_rect_h, p->tn, p->stream, /*dry_run=*/true);
+    if (fused) {
+    } else if (d_tap_col) {  // the pre-undistortion image is an API output: write it once, gather from it
       chain_dst = d_tap_col;
     } else {
       p->d_mid.reserve(mid_frame * (size_t)n);
@@ -720,10 +787,6 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     }
     chain_step = mid_pitch;
     chain_stride = mid_frame;
-    if (p->use_tiled_remap && (pl.channels == 3 || pl.channels == 1)) {
-      ensure_plan(p, pl.mid_rows, pl.mid_cols);
-      tiled = true;
-    }
   }
   if (pl.stage_bits & rip::ST_VIG) ensure_vignette(p, pl.mid_rows, pl.mid_cols);
 
@@ -850,39 +913,22 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
       rip::launch_wb_finalize(rip::WB_FLOAT, nullptr, cp.argmax, p->d_ccc_state.as<rip::CccState>(), cp.tabs, wb_g, ng, front);
     }
 
+    // ---- chain + remap in one kernel (memory-rate stage sets, no taps) ---------------------------------
+    if (fused) {
+      ProfScope ps(p, RIP_KERNEL_REMAP, front);
+      if (!rip::launch_remap_fused(tiled_params(in_g, in_step, in_frame_stride, rows, cols, f0, ng), chain_params(in_g, wb_g, ng), p->plan.max_rect_w,
+                                   p->plan.max_rect_h, p->tn, front, /*dry_run=*/false))
+        throw DeviceError("internal: the fused remap refused a geometry it had accepted");
+      continue;
+    }
     // ---- fused chain -----------------------------------------------------------------------------
-    rip::ChainParams c = {};
-    c.src = in_g;
-    c.src_step = in_step;
-    c.src_frame_stride = in_frame_stride;
-    c.rows = rows;
-    c.cols = cols;
-    c.src_kind = pl.src_kind;
-    c.bayer_ry = pl.ry;
-    c.bayer_rx = pl.rx;
+    rip::ChainParams c = chain_params(in_g, wb_g, ng);
     c.dst = chain_dst + (size_t)f0 * chain_stride;
     c.dst_step = chain_step;
     c.dst_frame_stride = chain_stride;
-    c.drows = pl.mid_rows;
-    c.dcols = pl.mid_cols;
-    c.channels = pl.channels;
     c.dst_streaming = (!pl.remap && n >= 8) ? 1 : 0;  // non-temporal stores for an image no kernel of this batch reads again (debayer-only, 256 frames: 1.08 against 1.16 ms)
     c.tap = d_tap_deb ? d_tap_deb + (size_t)f0 * tap_frame : nullptr;
     c.tap_frame_stride = tap_frame;
-    c.flip_angle = pl.flip_angle;
-    c.n_frames = ng;
-    c.wb_mode = pl.wb_mode;
-    c.wb = wb_g;
-    c.stage_bits = pl.stage_bits;
-    for (int i = 0; i < 9; i++) c.cc_m[i] = p->m.cc_matrix[i];
-    for (int i = 0; i < 3; i++) c.cc_bias[i] = (float)p->m.cc_bias[i];
-    if (pl.stage_bits & rip::ST_VIG) c.vig_mask = p->d_vig.as<float>();
-    // cv::Scalar(hue_gain_, saturation_gain_, value_gain_) on (H,S,V), color_enhancer.cpp:42
-    c.hsv_gain[0] = (float)p->m.ce_hue_gain;
-    c.hsv_gain[1] = (float)p->m.ce_saturation_gain;
-    c.hsv_gain[2] = (float)p->m.ce_value_gain;
-    c.tabs = p->d_tabs.as<rip::DevTables>();
-    c.vig_image = p->d_vig_image.as<uint32_t>();
     // overlap_mode 2: only the statistics of this group share the chip with the remap of the previous one; the chain waits
     if (back != front && p->tn.overlap_mode == 2 && g > 0) HIP_CHECK(hipStreamWaitEvent(front, p->ovl_events[groups + g - 1], 0));
     {
@@ -902,31 +948,10 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
         HIP_CHECK(hipStreamWaitEvent(back, p->ovl_events[g], 0));
         back_used = true;
       }
-      rip::RemapParams r = {};
-      r.src = c.dst;
-      r.src_step = mid_pitch;
-      r.src_frame_stride = mid_frame;
-      r.rows = pl.mid_rows;
-      r.cols = pl.mid_cols;
-      r.channels = pl.channels;
-      r.map_xy = p->d_map.as<float>();
-      r.dst = d_out + (size_t)f0 * out_frame_stride;
-      r.dst_step = out_step;
-      r.dst_frame_stride = out_frame_stride;
-      r.drows = pl.out_rows;
-      r.dcols = pl.out_cols;
-      r.n_frames = ng;
+      rip::RemapTiledParams tp = tiled_params(c.dst, mid_pitch, mid_frame, pl.mid_rows, pl.mid_cols, f0, ng);
+      const rip::RemapParams& r = tp.base;
       bool done = false;
       if (tiled) {
-        rip::RemapTiledParams tp = {};
-        tp.base = r;
-        tp.words = p->d_plan_words.as<uint32_t>();
-        tp.tiles = p->d_plan_tiles.as<rip::RemapTileDesc>();
-        tp.tiles_x = p->plan.tiles_x;
-        tp.tiles_y = p->plan.tiles_y;
-        tp.border_list = p->d_plan_border.as<uint32_t>();
-        tp.n_border = p->plan_n_border;
-        tp.lds_bytes = (unsigned)p->plan.max_lds_bytes;
         ProfScope ps(p, RIP_KERNEL_REMAP, back);
         done = rip::launch_remap_tiled(tp, p->tn, back);
       }
@@ -1067,6 +1092,7 @@ Tunables tunables_from_env() {
   t.remap_stages = positive("RIP_REMAP_STAGES", t.remap_stages);
   t.remap_per_cu = positive("RIP_REMAP_PER_CU", t.remap_per_cu);
   t.remap_frames = positive("RIP_REMAP_FRAMES", t.remap_frames);
+  if (const char* e = std::getenv("RIP_REMAP_FUSED")) t.remap_fused = std::atoi(e) != 0;
   t.ccc_lds_hist_min = positive("RIP_CCC_LDS_HIST_MIN", t.ccc_lds_hist_min);
   t.overlap_groups = positive("RIP_OVERLAP_GROUPS", t.overlap_groups);
   t.overlap_mode = positive("RIP_OVERLAP_MODE", t.overlap_mode);
@@ -1848,6 +1874,7 @@ rip_status rip_set_tunable(rip_pipeline* p, const char* name, int value) {
     else if (n == "remap_stages") t.remap_stages = value > 0 ? value : dflt.remap_stages;
     else if (n == "remap_per_cu") t.remap_per_cu = value;
     else if (n == "remap_frames") t.remap_frames = value;
+    else if (n == "remap_fused") t.remap_fused = value;
     else if (n == "remap_tiled") p->use_tiled_remap = value != 0;
     else if (n == "ccc_lds_hist_min") t.ccc_lds_hist_min = value > 0 ? value : dflt.ccc_lds_hist_min;
     else if (n == "overlap_groups") t.overlap_groups = value;

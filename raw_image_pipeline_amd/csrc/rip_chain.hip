@@ -2,6 +2,7 @@
 // ONE kernel, 1 B/px read, 3 B/px written, tables in LDS, no intermediate image between the stages.
 // Shared device code and the stage-by-stage reference citations: rip_device.hpp.
 #include "rip_device.hpp"
+#include "rip_chain_dev.hpp"
 
 #include <cstdio>
 
@@ -86,128 +87,6 @@ __global__ __launch_bounds__(kBlock) void debayer16_kernel(Debayer16Params p) {
     o[1] = (uint16_t)g;
     o[2] = (uint16_t)r;
   }
-}
-
-// Tables of the fast kernel in LDS: only what the compile-time stage set reads.
-template <bool ON, typename T>
-struct OptTab {
-  T v;
-};
-template <typename T>
-struct OptTab<false, T> {};
-struct GammaTab {
-  uint8_t lut[256];
-};
-struct HsvTab {
-  int32_t sdiv[256], hdiv[256];
-};
-template <int BITS>
-struct FastTabs {
-  static constexpr bool kVig = (BITS & ST_VIG) != 0;
-  static constexpr bool kHsv = (BITS & ST_HSV) != 0;
-  static constexpr bool kGamma = (BITS & ST_GAMMA) != 0 && !kVig;  // with vignetting the LUT is folded into VigTabs::lin
-  OptTab<kVig, VigTabs> vig;
-  OptTab<kGamma, GammaTab> gam;
-  OptTab<kHsv, HsvTab> hsv;
-  __device__ __forceinline__ int sdiv(int i) const {
-    if constexpr (kHsv) return hsv.v.sdiv[i];
-    return 0;
-  }
-  __device__ __forceinline__ int hdiv(int i) const {
-    if constexpr (kHsv) return hsv.v.hdiv[i];
-    return 0;
-  }
-  template <int NT>
-  __device__ __forceinline__ void load(const DevTables* t, const uint32_t* vig_image) {
-    if constexpr (kVig) {
-      if (vig_image)
-        vig.v.template load_image<NT>(vig_image);
-      else
-        vig.v.template load<NT>(t);
-    }
-    if constexpr (kGamma)
-      for (int i = threadIdx.x; i < 64; i += NT) reinterpret_cast<uint32_t*>(gam.v.lut)[i] = reinterpret_cast<const uint32_t*>(t->gamma_lut)[i];
-    if constexpr (kHsv)
-      for (int i = threadIdx.x; i < 256; i += NT) {
-        hsv.v.sdiv[i] = t->sdiv[i];
-        hsv.v.hdiv[i] = t->hdiv[i];
-      }
-  }
-};
-// workgroup size of the fast kernel: the Lab tables are 33 KB, so the vignetting variants share them among
-// 8 waves (3 workgroups = 24 waves per CU); the others keep 256 threads
-constexpr int kVigThreads = 512;
-constexpr int kVigWavesPerSimd = 6;  // waves per SIMD the register allocation must allow: 3 workgroups of 512 threads per CU
-template <int BITS>
-constexpr int fast_threads() {
-  return (BITS & ST_VIG) ? kVigThreads : 256;
-}
-template <int BITS>
-constexpr int fast_waves_per_simd() {
-  // vignetting + enhancer: 56 KB of tables, two workgroups per CU
-  return (BITS & ST_VIG) ? ((BITS & ST_HSV) ? 4 : kVigWavesPerSimd) : 1;
-}
-
-// The per-pixel stages after the demosaic for the four pixels of one row; returns the 12 interleaved output bytes.
-template <int BITS, int WB>
-__device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const CcRegs& cc,
-                                            const HsvRegs& hr, const float (&mask)[4], int (&q)[4][3]) {
-#pragma unroll
-  for (int k = 0; k < 4; k++) apply_wb(WB, w, q[k][0], q[k][1], q[k][2]);
-  if constexpr ((BITS & ST_VIG) != 0) {
-    // byte offsets into VigTabs::lin (gamma folded into that table by the host)
-    unsigned lin_off[4][3], out_idx[4][3];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if constexpr ((BITS & ST_CC) != 0) {
-        float o[3];
-        apply_cc_f(p, cc, q[k][0], q[k][1], q[k][2], o);
-        // saturate_cast<uchar> into byte 1 of the dword: (v << 8) >> 6 = 4 v, a full-rate right shift
-#pragma unroll
-        for (int c = 0; c < 3; c++) lin_off[k][c] = __builtin_amdgcn_cvt_pk_u8_f32(o[c], 1, 0u) >> 6;
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; c++) lin_off[k][c] = (unsigned)q[k][c] << 2;
-      }
-    }
-#pragma unroll
-    for (int k0 = 0; k0 < 4; k0 += kVigGroup) vignette_n<kVigGroup>(tb.vig.v, mask + k0, lin_off + k0, out_idx + k0);
-    if constexpr ((BITS & ST_HSV) == 0) return invg_pack4(out_idx);
-    invg_values4(out_idx, q);
-  } else {
-    if constexpr ((BITS & ST_CC) != 0 && (BITS & (ST_GAMMA | ST_HSV)) == 0) {
-      // the colour matrix is the last stage: its results are converted straight into their place in the packed output
-      float of[4][3];
-#pragma unroll
-      for (int k = 0; k < 4; k++) apply_cc_f(p, cc, q[k][0], q[k][1], q[k][2], of[k]);
-      return pack4_from_floats(of);
-    }
-    if constexpr ((BITS & ST_CC) != 0) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
-    }
-    if constexpr ((BITS & ST_GAMMA) != 0) {
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) q[k][c] = tb.gam.v.lut[q[k][c]];
-    }
-  }
-  if constexpr ((BITS & ST_HSV) != 0) {
-    float of[4][3];
-    if (hr.unit == 5u) {  // hue and value gains are 1 (the usual configuration scales the saturation only)
-      keep_branch();
-#pragma unroll
-      for (int k = 0; k < 4; k++) apply_hsv_f<5u>(hr.g, tb, q[k][0], q[k][1], q[k][2], of[k]);
-    } else {
-      asm volatile("s_nop 0 ; rip_generic_hsv_gains");  // marks the block for tools/chain_ledger.py (bench runs take the other one)
-#pragma unroll
-      for (int k = 0; k < 4; k++) apply_hsv_f<0u>(hr.g, tb, q[k][0], q[k][1], q[k][2], of[k]);
-      asm volatile("s_nop 0 ; rip_generic_hsv_end");
-    }
-    return pack4_from_floats(of);
-  }
-  return pack4(q);
 }
 
 template <int BITS, int WB, int NT>

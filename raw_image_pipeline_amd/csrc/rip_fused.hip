@@ -1,0 +1,335 @@
+// rip_fused.hip -- the per-pixel chain INSIDE the remap's tiles, for the stage sets that run at the memory rate.
+//
+// debayer -> (white-balance gains, colour matrix, gamma LUT) -> undistortion as two kernels moves 1 + 3 B/px through the
+// chain and 3 x 1.15 + 3 B/px (+ plan) through the remap: 11 B/px, seven of them for an intermediate image nobody asked for
+// (undistortion.cpp:240-249 gathers from the image flip.cpp / the colour modules left behind; the reference keeps it as
+// its dist_image_ tap).  When that tap is not requested, a remap tile can make its own source rectangle: the Bayer bytes
+// under the rectangle (1 B/px, a one-pixel halo) come in through the LDS-DMA ring, the workgroup demosaics and colours
+// them LDS -> LDS with the fused chain's own stage code (debayer_tile_any, pointwise4: same functions, same bits), and the
+// gather runs on that LDS image exactly as remap_ring_kernel's does.  Compulsory traffic: 1 B/px of Bayer (x the
+// rectangles' overlap) + 3 B/px written + the plan words -- 4 + 4 / n B/px instead of 11.  The demosaic of a rectangle
+// covers ~1.6 x the tile's pixels (overlap + alignment to 4 x 2 Bayer items); at ~5 VALU instructions per pixel that is
+// small beside the gather.
+//
+// Applies to: Bayer input on the fast geometry, no flip, no vignetting / enhancer (those stage sets are VALU-bound: the
+// 1.6 x recompute would cost more than the bytes save), tiled plan available, 16-byte-aligned Bayer pitch, and neither
+// the debayered nor the colour tap requested.  Everything else takes the two-kernel path.  Border pixels (taps straddling
+// the image edge) are patched per tap from the Bayer frame by remap_border_bayer_kernel.
+#include "rip_chain_dev.hpp"
+#include "rip_remap_dev.hpp"
+
+namespace rip {
+namespace {
+
+// LDS image of the visit's per-frame gains (FrameWb is read by every lane of every frame: one global read per visit)
+constexpr int kFusedMaxFrames = 16;
+
+// s_waitcnt for this wave's LDS writes, then the workgroup barrier: the raw s_barrier builtin does not wait for them, and a
+// __syncthreads() would also drain vmcnt, i.e. the ring's prefetched frames
+__device__ __forceinline__ void lds_write_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int PRE, int BITS, int WB>
+__global__ __launch_bounds__(kRemapTileThreads) void remap_bayer_ring_kernel(RemapTiledParams p, ChainParams c, unsigned bgr_off) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  __shared__ FastTabs<BITS> tb;
+  __shared__ FrameWb s_wb[kFusedMaxFrames];
+  constexpr unsigned kStage = (unsigned)PRE * kRemapTileThreads * 16u;  // bytes per Bayer stage
+  const RemapParams& b = p.base;  // b.src: the BAYER frames (1 B/px), b.rows / b.cols their geometry
+  tb.template load<kRemapTileThreads>(c.tabs, nullptr);
+  CcRegs cc = {};
+  if constexpr ((BITS & ST_CC) != 0) cc.load(c);
+  HsvRegs hr = {};
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const int tid = threadIdx.x;
+  const int lrow = tid / kRemapGroupsPerRow, lgrp = tid % kRemapGroupsPerRow;
+  const unsigned step = (unsigned)b.src_step;
+  const int f_per_group = (b.n_frames + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int f_begin = (int)blockIdx.y * f_per_group, f_end = min(b.n_frames, f_begin + f_per_group);
+  if (f_begin >= f_end) return;  // uniform for the workgroup
+  if (WB != WB_NONE)
+    for (int i = tid; i < f_end - f_begin; i += kRemapTileThreads) s_wb[i] = c.wb[f_begin + i];
+  __syncthreads();
+  const int nb = p.stages, dist = nb - 1;
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);
+  uint8_t* const bgr = lds + bgr_off;
+  const unsigned wave_chunk0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);
+  const unsigned dst_bytes = __umul24((unsigned)(b.drows - 1), (unsigned)b.dst_step) + (unsigned)b.dcols * 3u;
+  const unsigned src_bytes = __umul24((unsigned)(b.rows - 1), step) + (unsigned)b.cols;
+  const float ones[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+  for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
+    const int tile = xcd * per_xcd + ti;
+    if (tile >= ntiles) break;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const RemapTileDesc d = p.tiles[tile];
+    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * kRemapTilePx)[tid];
+    const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
+    const int yd = ty * kRemapTileH + lrow, xd = tx * kRemapTileW + lgrp * 4;
+    const bool in_image = yd < b.drows && xd < b.dcols;
+    // The rectangle widened to whole 4 x 2 Bayer items, and the Bayer bytes those items read (a dword left and right, a row
+    // above and below, clamped to the frame exactly as window_offsets clamps them), staged from a 16-byte-aligned column.
+    const int X0 = d.x0 & ~3, X1 = min((d.x0 + d.w + 3) & ~3, b.cols), Y0 = d.y0 & ~1, Y1 = min((d.y0 + d.h + 1) & ~1, b.rows);
+    const int BX0 = max(X0 - 4, 0), BX1 = min(X1 + 4, b.cols), BY0 = max(Y0 - 1, 0), BY1 = min(Y1 + 1, b.rows);
+    const unsigned CX0 = (unsigned)BX0 & ~15u;
+    const unsigned lp = ((unsigned)BX1 - CX0 + 15u) & ~15u;  // Bayer bytes per staged row
+    const unsigned chunks = lp >> 4;
+    const unsigned total = d.w > 0 ? chunks * (unsigned)(BY1 - BY0) : 0u;
+    const ItemMap cm{(int)chunks, 1.0f / (float)(chunks ? chunks : 1u)};
+    unsigned goff[PRE];
+#pragma unroll
+    for (int j = 0; j < PRE; j++) {
+      const unsigned i = (unsigned)tid + (unsigned)j * kRemapTileThreads;
+      int r, cc16;
+      cm.split((int)i, r, cc16);
+      goff[j] = i < total ? __umul24((unsigned)(BY0 + r), step) + CX0 + ((unsigned)cc16 << 4) : 0xFFFFFFF0u;
+    }
+    const unsigned bp = (unsigned)(X1 - X0) * 3u;  // bytes per row of the LDS colour image (a multiple of 12)
+    unsigned tap_addr[4], wxb[4], wyy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t w = words[k];
+      const bool live = w < kPlanBorder;
+      const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u, fy = w >> 27;
+      tap_addr[k] = live ? __umul24(rely + (unsigned)(d.y0 - Y0), bp) + (relx + (unsigned)(d.x0 - X0)) * 3u : 0u;
+      wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
+      wyy[k] = (32u - fy) | (fy << 16);
+    }
+    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u;
+    const int nx = (X1 - X0) >> 2, n_items = d.w > 0 ? nx * ((Y1 - Y0) >> 1) : 0;
+    const ItemMap im{nx, 1.0f / (float)(nx ? nx : 1)};
+
+    auto issue = [&](int f, int slot) {
+      const __amdgpu_buffer_rsrc_t rsrc = frame_rsrc(b.src + (size_t)f * b.src_frame_stride, src_bytes);
+      const unsigned stage = lds0 + (unsigned)slot * kStage;
+#pragma unroll
+      for (int j = 0; j < PRE; j++) lds_dma16(rsrc, goff[j], stage + ((wave_chunk0 + (unsigned)j * kRemapTileThreads) << 4));
+    };
+    // Bayer stage -> LDS colour image: the fused chain's item (4 px x 2 rows), its window read from LDS instead of HBM
+    auto demosaic = [&](const uint8_t* bay, int f) {
+      FrameWb w = {};
+      if (WB != WB_NONE) w = s_wb[f - f_begin];
+      for (int it = tid; it < n_items; it += kRemapTileThreads) {
+        int iy, ix;
+        im.split(it, iy, ix);
+        const int y = Y0 + 2 * iy, x = X0 + 4 * ix;
+        const int xl = x >= 4 ? x - 4 : x, xr = x + 4 < b.cols ? x + 4 : x;  // window_offsets' edge rule
+        Window win;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int yy = clampi(y - 1 + r, 0, b.rows - 1);
+          const uint8_t* row = bay + __umul24((unsigned)(yy - BY0), lp) - CX0;
+          win.w[r][0] = *reinterpret_cast<const uint32_t*>(row + xl);
+          win.w[r][1] = *reinterpret_cast<const uint32_t*>(row + x);
+          win.w[r][2] = *reinterpret_cast<const uint32_t*>(row + xr);
+        }
+        Planar rowpx[2];
+        debayer_tile_any(win, c.bayer_ry, c.bayer_rx, y, x, b.rows, b.cols, rowpx);
+#pragma unroll
+        for (int ly = 0; ly < 2; ly++) {
+          Planar v = rowpx[ly];
+          Pack3 o;
+          if (BITS == 0 && WB == WB_NONE) {
+            interleave4(v, o.a, o.b, o.c);
+          } else {
+            if (WB == WB_Q8) {
+              v.b = gains_q8_swar(v.b, (unsigned)w.q8[0]);
+              v.g = gains_q8_swar(v.g, (unsigned)w.q8[1]);
+              v.r = gains_q8_swar(v.r, (unsigned)w.q8[2]);
+            }
+            int q[4][3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              q[k][0] = (int)((v.b >> (8 * k)) & 0xFFu);
+              q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
+              q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
+            }
+            o = pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(c, w, tb, cc, hr, ones, q);
+          }
+          uint32_t* out = reinterpret_cast<uint32_t*>(bgr + __umul24((unsigned)(y + ly - Y0), bp) + (unsigned)(x - X0) * 3u);
+          out[0] = o.a;
+          out[1] = o.b;
+          out[2] = o.c;
+        }
+      }
+    };
+    auto gather_store = [&](int f) {
+      if (!in_image) return;
+      uint32_t t0[4], t1[4], b0[4], b1[4];  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        lds_load6(bgr, tap_addr[k], t0[k], t1[k]);
+        lds_load6(bgr, tap_addr[k] + bp, b0[k], b1[k]);
+      }
+      int q[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned wy0 = wyy[k] & 0xffffu, wy1 = wyy[k] >> 16;
+        const unsigned wB = wxb[k], wx0 = wB & 0xffu, wx1 = wB >> 24;
+        const unsigned wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
+        const unsigned topB = __builtin_amdgcn_udot4(t0[k], wB, 16u, false);
+        const unsigned topG = __builtin_amdgcn_udot4(t0[k], wG0, __builtin_amdgcn_udot4(t1[k], wx1, 16u, false), false);
+        const unsigned topR = __builtin_amdgcn_udot4(t0[k], wR0, __builtin_amdgcn_udot4(t1[k], wR1, 16u, false), false);
+        const unsigned botB = __builtin_amdgcn_udot4(b0[k], wB, 16u, false);
+        const unsigned botG = __builtin_amdgcn_udot4(b0[k], wG0, __builtin_amdgcn_udot4(b1[k], wx1, 16u, false), false);
+        const unsigned botR = __builtin_amdgcn_udot4(b0[k], wR0, __builtin_amdgcn_udot4(b1[k], wR1, 16u, false), false);
+        q[k][0] = blend_rows(topB, wy0, botB, wy1);
+        q[k][1] = blend_rows(topG, wy0, botG, wy1);
+        q[k][2] = blend_rows(topR, wy0, botR, wy1);
+      }
+      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, pack4(q));
+    };
+
+    // every earlier memory operation of this wave is waited for here, so the counted waits below see only this tile's ring
+    // loads and stores
+    wait_vmcnt<0>();
+    int slot_in = 0, slot_out = 0;
+    for (int f = f_begin; f < f_end && f < f_begin + dist; f++) {
+      issue(f, slot_in);
+      slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
+    }
+    for (int f = f_begin; f < f_end; f++) {
+      const int ahead = min(dist - 1, f_end - 1 - f);
+      if (ahead >= 2)
+        wait_vmcnt<2 * PRE>();
+      else if (ahead == 1)
+        wait_vmcnt<PRE>();
+      else
+        wait_vmcnt<0>();
+      // after this barrier: every wave's part of Bayer frame f is in LDS, and every wave has finished the gather of frame
+      // f - 1 (its LDS reads are consumed before its store is issued), so the colour image may be overwritten
+      __builtin_amdgcn_s_barrier();
+      if (f + dist < f_end) {
+        issue(f + dist, slot_in);
+        slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
+      }
+      demosaic(lds + (unsigned)slot_out * kStage, f);
+      slot_out = slot_out + 1 == nb ? 0 : slot_out + 1;
+      lds_write_barrier();
+      gather_store(f);
+    }
+    __builtin_amdgcn_s_barrier();  // the next tile's prologue refills stages and rewrites the colour image
+  }
+}
+
+// Border pixels of the plan (taps straddling the image edge): cv::remap's per-tap rule with BORDER_CONSTANT 0, every tap
+// demosaiced and coloured on the spot from the Bayer frame (debayer_at + the per-pixel stage functions: the same results as
+// the packed forms, as every parity test of the generic kernels shows).
+__global__ __launch_bounds__(kBlock) void remap_border_bayer_kernel(RemapTiledParams p, ChainParams c) {
+  const RemapParams& b = p.base;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.n_border) return;
+  const uint32_t packed = p.border_list[i];
+  const int yd = (int)(packed >> 16), xd = (int)(packed & 0xffffu);
+  const float2 m = reinterpret_cast<const float2*>(b.map_xy)[__umul24((unsigned)yd, (unsigned)b.dcols) + (unsigned)xd];
+  const int frame = blockIdx.y;
+  const SrcView s{b.src + (size_t)frame * b.src_frame_stride, b.src_step, b.rows, b.cols, SRC_BAYER, c.bayer_ry, c.bayer_rx};
+  const GlobalTabs tb{c.tabs};
+  FrameWb w = {};
+  if (c.wb_mode != WB_NONE) w = c.wb[frame];
+  const int sxq = round_map(m.x), syq = round_map(m.y);
+  const int sx = clampi(sxq >> 5, -32768, 32767), sy = clampi(syq >> 5, -32768, 32767);
+  const int fx = sxq & 31, fy = syq & 31;
+  const int wx[2] = {32 - fx, fx}, wy[2] = {32 - fy, fy};
+  int acc[3] = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    int rowsum[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int y = sy + j, x = sx + k;
+      if (y < 0 || y >= b.rows || x < 0 || x >= b.cols) continue;  // border constant 0
+      int pb, pg, pr;
+      fetch_src(s, y, x, pb, pg, pr);
+      pointwise<-1, -1>(c, w, tb, nullptr, nullptr, 1.0f, pb, pg, pr);
+      rowsum[0] += mul24(pb, wx[k]);
+      rowsum[1] += mul24(pg, wx[k]);
+      rowsum[2] += mul24(pr, wx[k]);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) acc[ch] += mul24(rowsum[ch], wy[j]);
+  }
+  uint8_t* o = b.dst + (size_t)frame * b.dst_frame_stride + (__umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u);
+  o[0] = (uint8_t)((acc[0] + 512) >> 10);
+  o[1] = (uint8_t)((acc[1] + 512) >> 10);
+  o[2] = (uint8_t)((acc[2] + 512) >> 10);
+}
+
+template <int PRE, int BITS>
+void launch_fused_wb(const RemapTiledParams& q, const ChainParams& c, unsigned bgr_off, dim3 grid, unsigned lds, hipStream_t stream) {
+  switch (c.wb_mode) {
+    case WB_Q8: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_Q8>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
+    case WB_FLOAT: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_FLOAT>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
+    case WB_PCA: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_PCA>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
+    case WB_SIMPLE: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_SIMPLE>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
+    default: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_NONE>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
+  }
+}
+template <int PRE>
+void launch_fused_bits(const RemapTiledParams& q, const ChainParams& c, unsigned bgr_off, dim3 grid, unsigned lds, hipStream_t stream) {
+  switch (c.stage_bits & 15) {
+    case 0: launch_fused_wb<PRE, 0>(q, c, bgr_off, grid, lds, stream); break;
+    case ST_CC: launch_fused_wb<PRE, ST_CC>(q, c, bgr_off, grid, lds, stream); break;
+    case ST_GAMMA: launch_fused_wb<PRE, ST_GAMMA>(q, c, bgr_off, grid, lds, stream); break;
+    default: launch_fused_wb<PRE, ST_CC | ST_GAMMA>(q, c, bgr_off, grid, lds, stream); break;
+  }
+}
+
+}  // namespace
+
+// p.base.src / src_step / src_frame_stride / rows / cols: the BAYER frames; c: the chain's stage parameters (wb, cc, tabs,
+// pattern).  max_rect_w / max_rect_h: the plan's largest source rectangle in pixels.  Returns false -- and launches nothing --
+// when the configuration or the geometry does not qualify; the caller then runs the chain and the remap as two kernels.
+bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max_rect_w, int max_rect_h, const Tunables& tn, hipStream_t stream,
+                        bool dry_run) {
+  const RemapParams& b = p.base;
+  if (b.n_frames <= 0) return true;
+  const bool ok = tn.remap_fused != 0 && tn.remap_ring != 0 && c.src_kind == SRC_BAYER && c.flip_angle == 0 &&
+                  (c.stage_bits & (ST_VIG | ST_HSV)) == 0 && c.tap == nullptr && b.channels == 3 &&
+                  bayer_fast_geometry(b.src, b.src_step, b.src_frame_stride, b.rows, b.cols, SRC_BAYER) && b.src_step % 16 == 0 &&
+                  b.src_frame_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(b.src) & 15u) == 0 && b.dcols % 4 == 0 && b.dst_step % 4 == 0 &&
+                  b.dst_frame_stride % 4 == 0 && aligned4(b.dst) && (reinterpret_cast<uintptr_t>(p.words) & 15u) == 0 &&
+                  b.dst_step < (1u << 24) && (unsigned long long)b.dst_step * (unsigned long long)b.drows < (1ull << 32) &&
+                  p.tiles_x * kRemapTileW >= b.dcols && p.tiles_y * kRemapTileH >= b.drows && b.drows <= 65535 && b.dcols <= 65535 &&
+                  max_rect_w > 0 && max_rect_h > 0;
+  if (!ok) return false;
+  // upper bounds of the two LDS images over all tiles (a rectangle widened to 4 x 2 items, a dword / a row of halo, the
+  // 16-byte alignment of the staged column)
+  const unsigned bayer_pitch = ((unsigned)max_rect_w + 3u + 3u + 8u + 15u + 15u) & ~15u;
+  const unsigned bayer_rows = (unsigned)max_rect_h + 1u + 2u + 1u;
+  const unsigned bayer_chunks = (bayer_pitch >> 4) * bayer_rows;
+  if (bayer_chunks > 4u * kRemapTileThreads) return false;
+  const int pre = bayer_chunks <= 1u * kRemapTileThreads ? 1 : (bayer_chunks <= 2u * kRemapTileThreads ? 2 : 4);
+  const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
+  const unsigned bgr_bytes = (((unsigned)max_rect_w + 6u) * 3u) * ((unsigned)max_rect_h + 2u) + 32u;  // + the tap reads' overrun
+  RemapTiledParams q = p;
+  q.stages = std::max(2, std::min(4, tn.remap_stages));
+  const unsigned bgr_off = (unsigned)q.stages * stage_bytes;
+  const unsigned lds = ((bgr_off + bgr_bytes) + 15u) & ~15u;
+  if (lds > 60u * 1024u) return false;
+  if (dry_run) return true;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int per_cu = std::max(1, std::min(tn.remap_per_cu > 0 ? tn.remap_per_cu : 6, (int)((160u * 1024u) / (lds + 2048u))));
+  int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
+  blocks = std::max(8, blocks / 8 * 8);
+  int frames_per_visit = tn.remap_frames;
+  if (frames_per_visit <= 0) {
+    // the frames of a visit are the Bayer frames now (a third of the bytes of the colour image): the same ~64 MB rule
+    const unsigned long long frame_bytes = (unsigned long long)b.src_step * (unsigned long long)b.rows * 3ull;
+    frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(4, ((64ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
+  }
+  frames_per_visit = std::min(frames_per_visit, kFusedMaxFrames);
+  int groups = std::max((256 * per_cu) / blocks, (b.n_frames + frames_per_visit - 1) / frames_per_visit);
+  groups = std::max(1, std::min(b.n_frames, groups));
+  const dim3 grid(blocks, groups);
+  if (pre == 1)
+    launch_fused_bits<1>(q, c, bgr_off, grid, lds, stream);
+  else if (pre == 2)
+    launch_fused_bits<2>(q, c, bgr_off, grid, lds, stream);
+  else
+    launch_fused_bits<4>(q, c, bgr_off, grid, lds, stream);
+  if (q.n_border > 0) hipLaunchKernelGGL(remap_border_bayer_kernel, dim3((q.n_border + 255) / 256, b.n_frames), dim3(256), 0, stream, q, c);
+  return true;
+}
+
+}  // namespace rip

@@ -222,6 +222,7 @@ struct Tunables {
   int remap_stages = 3;       // RIP_REMAP_STAGES: LDS ring size
   int remap_per_cu = 0;       // RIP_REMAP_PER_CU: resident workgroups per CU; 0 = 6 (ring) / 8 (tiled)
   int remap_frames = 0;       // RIP_REMAP_FRAMES: frames per tile visit (0: by the size of a source frame, 4 .. 12)
+  int remap_fused = 1;        // RIP_REMAP_FUSED=0: never run the chain inside the remap's tiles (rip_fused.hip)
   int ccc_lds_hist_min = 48;  // RIP_CCC_LDS_HIST_MIN: smallest batch that takes the LDS histogram
   int overlap_groups = 0;     // RIP_OVERLAP_GROUPS: frame groups a batch is split into on the handle's internal streams (rip_api.cpp run_batch); 0 / 1 = off (the measured optimum)
   int overlap_mode = 1;       // RIP_OVERLAP_MODE: 1 = remap(g) beside stats(g+1) + chain(g+1); 2 = beside stats(g+1) only (the chain waits)
@@ -232,6 +233,10 @@ Tunables tunables_from_env();  // rip_api.cpp; called by rip_create
 // ---- launchers (asynchronous on `stream`) -------------------------------------------------------
 // Returns false (and launches nothing) when the geometry does not qualify for the tiled kernel.
 bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream);
+// rip_fused.hip: debayer + memory-rate stages + remap in one kernel over the Bayer frames (p.base.src); false when the
+// configuration / geometry does not qualify (nothing launched).  dry_run: only answer.
+bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max_rect_w, int max_rect_h, const Tunables& tn, hipStream_t stream,
+                        bool dry_run);
 void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream);
 void launch_debayer16(const Debayer16Params& p, hipStream_t stream);
 // builds the image ChainParams::vig_image points to (vig_image_bytes() bytes) from the handle's tables

@@ -806,3 +806,49 @@ def test_mono8_fast_path_flip_gamma_undistortion(gpu_pipe, oracle, size, angle, 
     out = gpu_pipe.apply_device(dev, "mono8").cpu().numpy()
     for i in range(7):
         assert_images_equal(out[i].reshape(singles[i % 3].shape), singles[i % 3], "mono8 batch frame %d" % i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(64, 48), (256, 130), (644, 482), (1008, 502), (2448, 2048)])
+@pytest.mark.parametrize("pattern,wb,cc,gamma", [("bayer_rggb8", None, False, False), ("bayer_bggr8", "gray_world", True, True),
+                                                 ("bayer_gbrg8", "pca", False, True), ("bayer_grbg8", "simple", True, False),
+                                                 ("bayer_rggb8", "ccc", True, True)])
+def test_chain_inside_the_remap_tiles_equals_the_two_kernel_path(gpu_pipe, oracle, size, pattern, wb, cc, gamma):
+    """Memory-rate stage sets with no tap requested run debayer + gains + colour matrix + gamma INSIDE the remap's tiles
+    (rip_fused.hip: the Bayer bytes under a tile's source rectangle through the LDS-DMA ring, demosaiced LDS -> LDS, gathered
+    from there; undistortion.cpp:240-249 after debayer.cpp:45-79 / white_balance.cpp / color_calibration.cpp:93-103 /
+    gamma_correction.cpp).  A resident batch must equal the two-kernel path (remap_fused = 0) and the oracle bit for bit,
+    border pixels included; with the colour tap requested, or a Bayer pitch that is no multiple of 16, the fused path must
+    step aside."""
+    import torch
+    w, h = size
+    filt, bias = synth.ccc_model()
+    gpu_pipe.set_ccc_model(filt, bias)
+    gpu_pipe.set_ccc_kalman_model(1.0, 10.0)
+    c = cfg(wb=wb is not None, wb_method=wb or "gray_world", wb_bright=0.8, wb_dark=0.2, wb_temporal=False, cc=cc, cc_bias=(1.5, -2.0, 0.5) if cc and wb == "simple" else (0.0, 0.0, 0.0),
+            gamma=gamma, gamma_k=0.8, undistort=True, cam=synth.camera_model(w, h), balance=0.3, fov_scale=1.15)
+    configure(gpu_pipe, c)
+    frames = np.stack([synth.gen_frame(w, h, pattern, seed=5100 + i, kind="uniform" if i == 1 else "scene", tint=(0.6 + 0.07 * i, 1.0, 0.55)) for i in range(5)])
+    dev = torch.from_numpy(frames).cuda()
+    outs = {}
+    for fused in (1, 0):
+        gpu_pipe.set_tunable("remap_fused", fused)
+        gpu_pipe.profile_begin(64)
+        outs[fused] = gpu_pipe.apply_device(dev, pattern).cpu().numpy()
+        prof = gpu_pipe.profile_end()
+        # the fused path launches no chain kernel at all; it needs a 16-byte-aligned Bayer pitch (644 is not: two kernels)
+        assert (prof["chain"][1] == 0) == (fused == 1 and w % 16 == 0), (fused, prof)
+    assert np.array_equal(outs[1], outs[0]), "fused and two-kernel results differ on %d values" % int((outs[1] != outs[0]).sum())
+    occ = oracle.CCC(filt, bias) if wb == "ccc" else None
+    if occ is not None:
+        occ.set_kalman_model(1.0, 10.0)
+    for i in (0, 1, 4):
+        ref, _ = oracle_run(oracle, c, frames[i], pattern, ccc=occ)
+        assert_images_equal(outs[1][i], ref, "fused chain + remap, frame %d" % i)
+    # a requested tap needs the intermediate image: two kernels again, same result
+    gpu_pipe.set_tunable("remap_fused", 1)
+    tap = torch.empty((5, h, w, 3), dtype=torch.uint8, device="cuda")
+    gpu_pipe.profile_begin(64)
+    out_t = gpu_pipe.apply_device(dev, pattern, tap_color=tap).cpu().numpy()
+    assert gpu_pipe.profile_end()["chain"][1] > 0
+    assert np.array_equal(out_t, outs[1])
