@@ -21,6 +21,11 @@
 namespace rip {
 namespace {
 
+#ifndef RIP_FUSED_WAVES
+// waves per SIMD the register allocation must allow.  config5, ms per 256 frames: 4 waves (100-127 VGPRs as hipcc likes it) 3.44,
+// 5 (96 VGPRs, no spill in the frame loop) 3.20-3.25, 6 (80 VGPRs, 52-116 bytes of scratch) 4.40
+#define RIP_FUSED_WAVES 5
+#endif
 // LDS image of the visit's per-frame gains (FrameWb is read by every lane of every frame: one global read per visit)
 constexpr int kFusedMaxFrames = 16;
 
@@ -29,7 +34,7 @@ constexpr int kFusedMaxFrames = 16;
 __device__ __forceinline__ void lds_write_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int PRE, int BITS, int WB>
-__global__ __launch_bounds__(kRemapTileThreads) void remap_bayer_ring_kernel(RemapTiledParams p, ChainParams c, unsigned bgr_off) {
+__global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_bayer_ring_kernel(RemapTiledParams p, ChainParams c, unsigned bgr_off, unsigned bgr_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   __shared__ FastTabs<BITS> tb;
   __shared__ FrameWb s_wb[kFusedMaxFrames];
@@ -98,6 +103,27 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_bayer_ring_kernel(Rem
     const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u;
     const int nx = (X1 - X0) >> 2, n_items = d.w > 0 ? nx * ((Y1 - Y0) >> 1) : 0;
     const ItemMap im{nx, 1.0f / (float)(nx ? nx : 1)};
+    // frame-invariant part of a demosaic item: LDS offsets of the four window rows at the centre dword, the distances to the
+    // left / right dwords (0 at the image's edges: window_offsets' rule), the offset of the item's first output row in the
+    // colour image, and its position for the border rule.  The lane's FIRST item is kept in registers across the frames of
+    // the visit (all there is for the usual rectangles: <= 256 items); further items of large rectangles are recomputed.
+    struct Item {
+      unsigned row[4], lr, out;
+      int y, x;
+    };
+    auto make_item = [&](int it) {
+      Item e;
+      int iy, ix;
+      im.split(it, iy, ix);
+      e.y = Y0 + 2 * iy;
+      e.x = X0 + 4 * ix;
+      e.lr = (e.x >= 4 ? 4u : 0u) | ((e.x + 4 < b.cols ? 4u : 0u) << 16);
+#pragma unroll
+      for (int r = 0; r < 4; r++) e.row[r] = __umul24((unsigned)(clampi(e.y - 1 + r, 0, b.rows - 1) - BY0), lp) + (unsigned)e.x - CX0;
+      e.out = __umul24((unsigned)(e.y - Y0), bp) + (unsigned)(e.x - X0) * 3u;
+      return e;
+    };
+    const Item item0 = make_item(tid < n_items ? tid : 0);
 
     auto issue = [&](int f, int slot) {
       const __amdgpu_buffer_rsrc_t rsrc = frame_rsrc(b.src + (size_t)f * b.src_frame_stride, src_bytes);
@@ -106,60 +132,60 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_bayer_ring_kernel(Rem
       for (int j = 0; j < PRE; j++) lds_dma16(rsrc, goff[j], stage + ((wave_chunk0 + (unsigned)j * kRemapTileThreads) << 4));
     };
     // Bayer stage -> LDS colour image: the fused chain's item (4 px x 2 rows), its window read from LDS instead of HBM
-    auto demosaic = [&](const uint8_t* bay, int f) {
-      FrameWb w = {};
-      if (WB != WB_NONE) w = s_wb[f - f_begin];
-      for (int it = tid; it < n_items; it += kRemapTileThreads) {
-        int iy, ix;
-        im.split(it, iy, ix);
-        const int y = Y0 + 2 * iy, x = X0 + 4 * ix;
-        const int xl = x >= 4 ? x - 4 : x, xr = x + 4 < b.cols ? x + 4 : x;  // window_offsets' edge rule
-        Window win;
+    auto demosaic_item = [&](const uint8_t* bay, uint8_t* img, const FrameWb& w, const Item& e) {
+      const unsigned dl = e.lr & 0xffffu, dr = e.lr >> 16;
+      Window win;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int yy = clampi(y - 1 + r, 0, b.rows - 1);
-          const uint8_t* row = bay + __umul24((unsigned)(yy - BY0), lp) - CX0;
-          win.w[r][0] = *reinterpret_cast<const uint32_t*>(row + xl);
-          win.w[r][1] = *reinterpret_cast<const uint32_t*>(row + x);
-          win.w[r][2] = *reinterpret_cast<const uint32_t*>(row + xr);
-        }
-        Planar rowpx[2];
-        debayer_tile_any(win, c.bayer_ry, c.bayer_rx, y, x, b.rows, b.cols, rowpx);
+      for (int r = 0; r < 4; r++) {
+        const uint8_t* row = bay + e.row[r];
+        win.w[r][0] = *reinterpret_cast<const uint32_t*>(row - dl);
+        win.w[r][1] = *reinterpret_cast<const uint32_t*>(row);
+        win.w[r][2] = *reinterpret_cast<const uint32_t*>(row + dr);
+      }
+      Planar rowpx[2];
+      debayer_tile_any(win, c.bayer_ry, c.bayer_rx, e.y, e.x, b.rows, b.cols, rowpx);
 #pragma unroll
-        for (int ly = 0; ly < 2; ly++) {
-          Planar v = rowpx[ly];
-          Pack3 o;
-          if (BITS == 0 && WB == WB_NONE) {
-            interleave4(v, o.a, o.b, o.c);
-          } else {
-            if (WB == WB_Q8) {
-              v.b = gains_q8_swar(v.b, (unsigned)w.q8[0]);
-              v.g = gains_q8_swar(v.g, (unsigned)w.q8[1]);
-              v.r = gains_q8_swar(v.r, (unsigned)w.q8[2]);
-            }
-            int q[4][3];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              q[k][0] = (int)((v.b >> (8 * k)) & 0xFFu);
-              q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
-              q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
-            }
-            o = pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(c, w, tb, cc, hr, ones, q);
+      for (int ly = 0; ly < 2; ly++) {
+        Planar v = rowpx[ly];
+        Pack3 o;
+        if (BITS == 0 && WB == WB_NONE) {
+          interleave4(v, o.a, o.b, o.c);
+        } else {
+          if (WB == WB_Q8) {
+            v.b = gains_q8_swar(v.b, (unsigned)w.q8[0]);
+            v.g = gains_q8_swar(v.g, (unsigned)w.q8[1]);
+            v.r = gains_q8_swar(v.r, (unsigned)w.q8[2]);
           }
-          uint32_t* out = reinterpret_cast<uint32_t*>(bgr + __umul24((unsigned)(y + ly - Y0), bp) + (unsigned)(x - X0) * 3u);
-          out[0] = o.a;
-          out[1] = o.b;
-          out[2] = o.c;
+          int q[4][3];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            q[k][0] = (int)((v.b >> (8 * k)) & 0xFFu);
+            q[k][1] = (int)((v.g >> (8 * k)) & 0xFFu);
+            q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
+          }
+          o = pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(c, w, tb, cc, hr, ones, q);
         }
+        uint32_t* out = reinterpret_cast<uint32_t*>(img + e.out + (ly ? bp : 0u));
+        out[0] = o.a;
+        out[1] = o.b;
+        out[2] = o.c;
       }
     };
-    auto gather_store = [&](int f) {
+    // Bayer stage -> LDS colour image: the fused chain's item (4 px x 2 rows), its window read from LDS instead of HBM
+    auto demosaic = [&](const uint8_t* bay, uint8_t* img, int f) {
+      FrameWb w = {};
+      if (WB != WB_NONE) w = s_wb[f - f_begin];
+      if (tid < n_items) demosaic_item(bay, img, w, item0);
+#pragma unroll 1
+      for (int it = tid + kRemapTileThreads; it < n_items; it += kRemapTileThreads) demosaic_item(bay, img, w, make_item(it));
+    };
+    auto gather_store = [&](const uint8_t* img, int f) {
       if (!in_image) return;
       uint32_t t0[4], t1[4], b0[4], b1[4];  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        lds_load6(bgr, tap_addr[k], t0[k], t1[k]);
-        lds_load6(bgr, tap_addr[k] + bp, b0[k], b1[k]);
+        lds_load6(img, tap_addr[k], t0[k], t1[k]);
+        lds_load6(img, tap_addr[k] + bp, b0[k], b1[k]);
       }
       int q[4][3];
 #pragma unroll
@@ -179,16 +205,7 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_bayer_ring_kernel(Rem
       }
       store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, pack4(q));
     };
-
-    // every earlier memory operation of this wave is waited for here, so the counted waits below see only this tile's ring
-    // loads and stores
-    wait_vmcnt<0>();
-    int slot_in = 0, slot_out = 0;
-    for (int f = f_begin; f < f_end && f < f_begin + dist; f++) {
-      issue(f, slot_in);
-      slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
-    }
-    for (int f = f_begin; f < f_end; f++) {
+    auto wait_landed = [&](int f) {  // the Bayer bytes of frame f are in LDS (this wave's part): frames issued after f may fly
       const int ahead = min(dist - 1, f_end - 1 - f);
       if (ahead >= 2)
         wait_vmcnt<2 * PRE>();
@@ -196,19 +213,46 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_bayer_ring_kernel(Rem
         wait_vmcnt<PRE>();
       else
         wait_vmcnt<0>();
-      // after this barrier: every wave's part of Bayer frame f is in LDS, and every wave has finished the gather of frame
-      // f - 1 (its LDS reads are consumed before its store is issued), so the colour image may be overwritten
-      __builtin_amdgcn_s_barrier();
-      if (f + dist < f_end) {
-        issue(f + dist, slot_in);
+    };
+
+    // every earlier memory operation of this wave is waited for here, so the counted waits below see only this tile's ring
+    // loads and stores
+    wait_vmcnt<0>();
+    // Skewed by one frame, ONE barrier per frame: between two barriers a workgroup demosaics frame f + 1 into one colour
+    // image while it gathers frame f from the other.  The barrier of iteration f says: every wave's part of Bayer frame
+    // f + 1 has landed; colour image f is complete (every wave waited for its LDS writes); everybody is done gathering frame
+    // f - 1, so its colour image may take frame f + 1; and everybody is done demosaicing frame f, so its Bayer stage may be
+    // refilled.
+    int slot_in = 0, slot_dem = 0;  // ring positions of the next frame to issue / to demosaic
+    for (int f = f_begin; f < f_end && f < f_begin + dist; f++) {
+      issue(f, slot_in);
+      slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
+    }
+    wait_landed(f_begin);
+    __builtin_amdgcn_s_barrier();
+    if (f_begin + dist < f_end) {
+      issue(f_begin + dist, slot_in);
+      slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
+    }
+    demosaic(lds + (unsigned)slot_dem * kStage, bgr, f_begin);
+    slot_dem = slot_dem + 1 == nb ? 0 : slot_dem + 1;
+    for (int f = f_begin; f < f_end; f++) {
+      const bool more = f + 1 < f_end;
+      if (more) wait_landed(f + 1);
+      lds_write_barrier();
+      if (f + 1 + dist < f_end) {
+        issue(f + 1 + dist, slot_in);
         slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
       }
-      demosaic(lds + (unsigned)slot_out * kStage, f);
-      slot_out = slot_out + 1 == nb ? 0 : slot_out + 1;
-      lds_write_barrier();
-      gather_store(f);
+      uint8_t* const img_f = bgr + (((f - f_begin) & 1) ? bgr_bytes : 0u);
+      uint8_t* const img_n = bgr + (((f - f_begin) & 1) ? 0u : bgr_bytes);
+      if (more) {
+        demosaic(lds + (unsigned)slot_dem * kStage, img_n, f + 1);
+        slot_dem = slot_dem + 1 == nb ? 0 : slot_dem + 1;
+      }
+      gather_store(img_f, f);
     }
-    __builtin_amdgcn_s_barrier();  // the next tile's prologue refills stages and rewrites the colour image
+    lds_write_barrier();  // the next tile's prologue refills the stages and rewrites the colour images
   }
 }
 
@@ -256,22 +300,22 @@ __global__ __launch_bounds__(kBlock) void remap_border_bayer_kernel(RemapTiledPa
 }
 
 template <int PRE, int BITS>
-void launch_fused_wb(const RemapTiledParams& q, const ChainParams& c, unsigned bgr_off, dim3 grid, unsigned lds, hipStream_t stream) {
+void launch_fused_wb(const RemapTiledParams& q, const ChainParams& c, unsigned bgr_off, unsigned bgr_bytes, dim3 grid, unsigned lds, hipStream_t stream) {
   switch (c.wb_mode) {
-    case WB_Q8: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_Q8>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
-    case WB_FLOAT: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_FLOAT>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
-    case WB_PCA: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_PCA>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
-    case WB_SIMPLE: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_SIMPLE>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
-    default: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_NONE>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off); break;
+    case WB_Q8: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_Q8>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off, bgr_bytes); break;
+    case WB_FLOAT: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_FLOAT>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off, bgr_bytes); break;
+    case WB_PCA: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_PCA>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off, bgr_bytes); break;
+    case WB_SIMPLE: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_SIMPLE>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off, bgr_bytes); break;
+    default: hipLaunchKernelGGL((remap_bayer_ring_kernel<PRE, BITS, WB_NONE>), grid, dim3(kRemapTileThreads), lds, stream, q, c, bgr_off, bgr_bytes); break;
   }
 }
 template <int PRE>
-void launch_fused_bits(const RemapTiledParams& q, const ChainParams& c, unsigned bgr_off, dim3 grid, unsigned lds, hipStream_t stream) {
+void launch_fused_bits(const RemapTiledParams& q, const ChainParams& c, unsigned bgr_off, unsigned bgr_bytes, dim3 grid, unsigned lds, hipStream_t stream) {
   switch (c.stage_bits & 15) {
-    case 0: launch_fused_wb<PRE, 0>(q, c, bgr_off, grid, lds, stream); break;
-    case ST_CC: launch_fused_wb<PRE, ST_CC>(q, c, bgr_off, grid, lds, stream); break;
-    case ST_GAMMA: launch_fused_wb<PRE, ST_GAMMA>(q, c, bgr_off, grid, lds, stream); break;
-    default: launch_fused_wb<PRE, ST_CC | ST_GAMMA>(q, c, bgr_off, grid, lds, stream); break;
+    case 0: launch_fused_wb<PRE, 0>(q, c, bgr_off, bgr_bytes, grid, lds, stream); break;
+    case ST_CC: launch_fused_wb<PRE, ST_CC>(q, c, bgr_off, bgr_bytes, grid, lds, stream); break;
+    case ST_GAMMA: launch_fused_wb<PRE, ST_GAMMA>(q, c, bgr_off, bgr_bytes, grid, lds, stream); break;
+    default: launch_fused_wb<PRE, ST_CC | ST_GAMMA>(q, c, bgr_off, bgr_bytes, grid, lds, stream); break;
   }
 }
 
@@ -301,33 +345,32 @@ bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max
   if (bayer_chunks > 4u * kRemapTileThreads) return false;
   const int pre = bayer_chunks <= 1u * kRemapTileThreads ? 1 : (bayer_chunks <= 2u * kRemapTileThreads ? 2 : 4);
   const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
-  const unsigned bgr_bytes = (((unsigned)max_rect_w + 6u) * 3u) * ((unsigned)max_rect_h + 2u) + 32u;  // + the tap reads' overrun
+  // one colour image (+ the tap reads' overrun), 16-byte granules; two of them: frame f + 1 is demosaiced while frame f is gathered
+  const unsigned bgr_bytes = ((((unsigned)max_rect_w + 6u) * 3u) * ((unsigned)max_rect_h + 2u) + 32u + 15u) & ~15u;
   RemapTiledParams q = p;
   q.stages = std::max(2, std::min(4, tn.remap_stages));
   const unsigned bgr_off = (unsigned)q.stages * stage_bytes;
-  const unsigned lds = ((bgr_off + bgr_bytes) + 15u) & ~15u;
+  const unsigned lds = ((bgr_off + 2u * bgr_bytes) + 15u) & ~15u;
   if (lds > 60u * 1024u) return false;
   if (dry_run) return true;
   const int ntiles = p.tiles_x * p.tiles_y;
   const int per_cu = std::max(1, std::min(tn.remap_per_cu > 0 ? tn.remap_per_cu : 6, (int)((160u * 1024u) / (lds + 2048u))));
   int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
   blocks = std::max(8, blocks / 8 * 8);
-  int frames_per_visit = tn.remap_frames;
-  if (frames_per_visit <= 0) {
-    // the frames of a visit are the Bayer frames now (a third of the bytes of the colour image): the same ~64 MB rule
-    const unsigned long long frame_bytes = (unsigned long long)b.src_step * (unsigned long long)b.rows * 3ull;
-    frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(4, ((64ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
-  }
+  // frames per tile visit: the per-tile set-up (item geometry, plan words: a quarter of the traffic at 4 frames per visit)
+  // is paid once per visit and the Bayer frames of a visit are small, so long visits win -- config5, ms per 256 frames at
+  // 2 / 3 / 4 / 6 / 8 / 12 / 16 frames per visit: 5.04 / 4.42 / 4.08 / 3.77 / 3.70 / 3.53 / 3.47
+  int frames_per_visit = tn.remap_frames > 0 ? tn.remap_frames : kFusedMaxFrames;
   frames_per_visit = std::min(frames_per_visit, kFusedMaxFrames);
   int groups = std::max((256 * per_cu) / blocks, (b.n_frames + frames_per_visit - 1) / frames_per_visit);
   groups = std::max(1, std::min(b.n_frames, groups));
   const dim3 grid(blocks, groups);
   if (pre == 1)
-    launch_fused_bits<1>(q, c, bgr_off, grid, lds, stream);
+    launch_fused_bits<1>(q, c, bgr_off, bgr_bytes, grid, lds, stream);
   else if (pre == 2)
-    launch_fused_bits<2>(q, c, bgr_off, grid, lds, stream);
+    launch_fused_bits<2>(q, c, bgr_off, bgr_bytes, grid, lds, stream);
   else
-    launch_fused_bits<4>(q, c, bgr_off, grid, lds, stream);
+    launch_fused_bits<4>(q, c, bgr_off, bgr_bytes, grid, lds, stream);
   if (q.n_border > 0) hipLaunchKernelGGL(remap_border_bayer_kernel, dim3((q.n_border + 255) / 256, b.n_frames), dim3(256), 0, stream, q, c);
   return true;
 }
