@@ -11,7 +11,7 @@
 // covers ~1.6 x the tile's pixels (overlap + alignment to 4 x 2 Bayer items); at ~5 VALU instructions per pixel that is
 // small beside the gather.
 //
-// Applies to: Bayer input on the fast geometry, no flip, no vignetting / enhancer (those stage sets are VALU-bound: the
+// Applies to: Bayer input on the fast geometry, flip 0 / 180, no vignetting / enhancer (those stage sets are VALU-bound: the
 // 1.6 x recompute would cost more than the bytes save), tiled plan available, 16-byte-aligned Bayer pitch, and neither
 // the debayered nor the colour tap requested.  Everything else takes the two-kernel path.  Border pixels (taps straddling
 // the image edge) are patched per tap from the Bayer frame by remap_border_bayer_kernel.
@@ -74,7 +74,13 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
     const bool in_image = yd < b.drows && xd < b.dcols;
     // The rectangle widened to whole 4 x 2 Bayer items, and the Bayer bytes those items read (a dword left and right, a row
     // above and below, clamped to the frame exactly as window_offsets clamps them), staged from a 16-byte-aligned column.
-    const int X0 = d.x0 & ~3, X1 = min((d.x0 + d.w + 3) & ~3, b.cols), Y0 = d.y0 & ~1, Y1 = min((d.y0 + d.h + 1) & ~1, b.rows);
+    // With a 180-degree flip the image the remap gathers from is the demosaiced frame read backwards: image pixel (y, x) is
+    // frame pixel (rows - 1 - y, cols - 1 - x).  The LDS colour image stays in FRAME orientation (the demosaic and the stage
+    // code do not change); the tile's rectangle is mirrored into frame coordinates here, and the taps below address it
+    // backwards.
+    const bool flip = c.flip_angle == 180;
+    const int rx0 = flip ? b.cols - d.x0 - d.w : d.x0, ry0 = flip ? b.rows - d.y0 - d.h : d.y0;
+    const int X0 = rx0 & ~3, X1 = min((rx0 + d.w + 3) & ~3, b.cols), Y0 = ry0 & ~1, Y1 = min((ry0 + d.h + 1) & ~1, b.rows);
     const int BX0 = max(X0 - 4, 0), BX1 = min(X1 + 4, b.cols), BY0 = max(Y0 - 1, 0), BY1 = min(Y1 + 1, b.rows);
     const unsigned CX0 = (unsigned)BX0 & ~15u;
     const unsigned lp = ((unsigned)BX1 - CX0 + 15u) & ~15u;  // Bayer bytes per staged row
@@ -96,9 +102,18 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
       const uint32_t w = words[k];
       const bool live = w < kPlanBorder;
       const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u, fy = w >> 27;
-      tap_addr[k] = live ? __umul24(rely + (unsigned)(d.y0 - Y0), bp) + (relx + (unsigned)(d.x0 - X0)) * 3u : 0u;
-      wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
-      wyy[k] = (32u - fy) | (fy << 16);
+      if (!flip) {
+        tap_addr[k] = live ? __umul24(rely + (unsigned)(ry0 - Y0), bp) + (relx + (unsigned)(rx0 - X0)) * 3u : 0u;
+        wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
+        wyy[k] = (32u - fy) | (fy << 16);
+      } else {
+        // the tap square {y, y + 1} x {x, x + 1} of the image is the frame square whose top-left pixel is
+        // (rows - 2 - y, cols - 2 - x), read upside down and mirrored: the weights change places
+        const int sy = b.rows - 2 - (d.y0 + (int)rely), sx = b.cols - 2 - (d.x0 + (int)relx);
+        tap_addr[k] = live ? __umul24((unsigned)(sy - Y0), bp) + (unsigned)(sx - X0) * 3u : 0u;
+        wxb[k] = live ? fx | ((32u - fx) << 24) : 0u;
+        wyy[k] = fy | ((32u - fy) << 16);
+      }
     }
     const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * 3u;
     const int nx = (X1 - X0) >> 2, n_items = d.w > 0 ? nx * ((Y1 - Y0) >> 1) : 0;
@@ -284,7 +299,10 @@ __global__ __launch_bounds__(kBlock) void remap_border_bayer_kernel(RemapTiledPa
       const int y = sy + j, x = sx + k;
       if (y < 0 || y >= b.rows || x < 0 || x >= b.cols) continue;  // border constant 0
       int pb, pg, pr;
-      fetch_src(s, y, x, pb, pg, pr);
+      if (c.flip_angle == 180)
+        fetch_src(s, b.rows - 1 - y, b.cols - 1 - x, pb, pg, pr);
+      else
+        fetch_src(s, y, x, pb, pg, pr);
       pointwise<-1, -1>(c, w, tb, nullptr, nullptr, 1.0f, pb, pg, pr);
       rowsum[0] += mul24(pb, wx[k]);
       rowsum[1] += mul24(pg, wx[k]);
@@ -328,7 +346,7 @@ bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max
                         bool dry_run) {
   const RemapParams& b = p.base;
   if (b.n_frames <= 0) return true;
-  const bool ok = tn.remap_fused != 0 && tn.remap_ring != 0 && c.src_kind == SRC_BAYER && c.flip_angle == 0 &&
+  const bool ok = tn.remap_fused != 0 && tn.remap_ring != 0 && c.src_kind == SRC_BAYER && (c.flip_angle == 0 || c.flip_angle == 180) &&
                   (c.stage_bits & (ST_VIG | ST_HSV)) == 0 && c.tap == nullptr && b.channels == 3 &&
                   bayer_fast_geometry(b.src, b.src_step, b.src_frame_stride, b.rows, b.cols, SRC_BAYER) && b.src_step % 16 == 0 &&
                   b.src_frame_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(b.src) & 15u) == 0 && b.dcols % 4 == 0 && b.dst_step % 4 == 0 &&

@@ -810,10 +810,10 @@ def test_mono8_fast_path_flip_gamma_undistortion(gpu_pipe, oracle, size, angle, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("size", [(64, 48), (256, 130), (644, 482), (1008, 502), (2448, 2048)])
-@pytest.mark.parametrize("pattern,wb,cc,gamma", [("bayer_rggb8", None, False, False), ("bayer_bggr8", "gray_world", True, True),
-                                                 ("bayer_gbrg8", "pca", False, True), ("bayer_grbg8", "simple", True, False),
-                                                 ("bayer_rggb8", "ccc", True, True)])
-def test_chain_inside_the_remap_tiles_equals_the_two_kernel_path(gpu_pipe, oracle, size, pattern, wb, cc, gamma):
+@pytest.mark.parametrize("pattern,wb,cc,gamma,angle", [("bayer_rggb8", None, False, False, 0), ("bayer_bggr8", "gray_world", True, True, 0),
+                                                       ("bayer_gbrg8", "pca", False, True, 180), ("bayer_grbg8", "simple", True, False, 0),
+                                                       ("bayer_rggb8", "ccc", True, True, 180), ("bayer_grbg8", None, False, False, 180)])
+def test_chain_inside_the_remap_tiles_equals_the_two_kernel_path(gpu_pipe, oracle, size, pattern, wb, cc, gamma, angle):
     """Memory-rate stage sets with no tap requested run debayer + gains + colour matrix + gamma INSIDE the remap's tiles
     (rip_fused.hip: the Bayer bytes under a tile's source rectangle through the LDS-DMA ring, demosaiced LDS -> LDS, gathered
     from there; undistortion.cpp:240-249 after debayer.cpp:45-79 / white_balance.cpp / color_calibration.cpp:93-103 /
@@ -825,7 +825,8 @@ def test_chain_inside_the_remap_tiles_equals_the_two_kernel_path(gpu_pipe, oracl
     filt, bias = synth.ccc_model()
     gpu_pipe.set_ccc_model(filt, bias)
     gpu_pipe.set_ccc_kalman_model(1.0, 10.0)
-    c = cfg(wb=wb is not None, wb_method=wb or "gray_world", wb_bright=0.8, wb_dark=0.2, wb_temporal=False, cc=cc, cc_bias=(1.5, -2.0, 0.5) if cc and wb == "simple" else (0.0, 0.0, 0.0),
+    c = cfg(flip=angle != 0, flip_angle=angle, wb=wb is not None, wb_method=wb or "gray_world", wb_bright=0.8, wb_dark=0.2, wb_temporal=False, cc=cc,
+            cc_bias=(1.5, -2.0, 0.5) if cc and wb == "simple" else (0.0, 0.0, 0.0),
             gamma=gamma, gamma_k=0.8, undistort=True, cam=synth.camera_model(w, h), balance=0.3, fov_scale=1.15)
     configure(gpu_pipe, c)
     frames = np.stack([synth.gen_frame(w, h, pattern, seed=5100 + i, kind="uniform" if i == 1 else "scene", tint=(0.6 + 0.07 * i, 1.0, 0.55)) for i in range(5)])
