@@ -709,7 +709,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   }
   uint8_t* chain_dst = d_out;
   size_t chain_step = out_step, chain_stride = out_frame_stride;
-  bool tiled = false, fused = false;
+  bool tiled = false, fused = false, direct = false;
   // the remap's view of one group of frames: plan, destination, and -- `src` -- either the intermediate image or, on the
   // fused path, the Bayer frames themselves
   auto tiled_params = [&](const uint8_t* src, size_t src_step, size_t src_frame_stride, int src_rows, int src_cols, int f0, int ng) {
@@ -778,7 +778,11 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     if (tiled && !d_tap_col && !d_tap_deb && pl.src_kind == rip::SRC_BAYER)
       fused = rip::launch_remap_fused(tiled_params(d_in, in_step, in_frame_stride, rows, cols, 0, n), chain_params(d_in, p->d_wb.as<rip::FrameWb>(), n),
                                       p->plan.max_rect_w, p->plan.max_rect_h, p->tn, p->stream, /*dry_run=*/true);
-    if (fused) {
+    // bgr8 / mono8 frames with nothing to do before the undistortion (no flip, no white balance, no stage, no tap): the
+    // chain would be a copy -- the remap gathers from the caller's frames as they lie
+    direct = !fused && !d_tap_col && !d_tap_deb && (pl.src_kind == rip::SRC_BGR || pl.src_kind == rip::SRC_MONO) && pl.flip_angle == 0 &&
+             pl.wb_mode == rip::WB_NONE && pl.stage_bits == 0;
+    if (fused || direct) {
     } else if (d_tap_col) {  // the pre-undistortion image is an API output: write it once, gather from it
       chain_dst = d_tap_col;
     } else {
@@ -923,6 +927,13 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     }
     // ---- fused chain -----------------------------------------------------------------------------
     rip::ChainParams c = chain_params(in_g, wb_g, ng);
+    if (direct) {  // no chain at all: the remap below reads the input frames
+      ProfScope ps(p, RIP_KERNEL_REMAP, front);
+      rip::RemapTiledParams tp = tiled_params(in_g, in_step, in_frame_stride, rows, cols, f0, ng);
+      if (!(tiled && rip::launch_remap_tiled(tp, p->tn, front)) && !rip::launch_remap(tp.base, front))
+        throw InvalidArgument("undistortion: frame geometry exceeds the kernels' 32-bit addressing");
+      continue;
+    }
     c.dst = chain_dst + (size_t)f0 * chain_stride;
     c.dst_step = chain_step;
     c.dst_frame_stride = chain_stride;

@@ -853,3 +853,27 @@ def test_chain_inside_the_remap_tiles_equals_the_two_kernel_path(gpu_pipe, oracl
     out_t = gpu_pipe.apply_device(dev, pattern, tap_color=tap).cpu().numpy()
     assert gpu_pipe.profile_end()["chain"][1] > 0
     assert np.array_equal(out_t, outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoding", ["bgr8", "mono8", "rgb8"])
+@pytest.mark.parametrize("size", [(64, 48), (132, 36), (640, 480)])
+def test_undistortion_alone_gathers_from_the_input_frames(gpu_pipe, oracle, encoding, size):
+    """bgr8 / mono8 frames with nothing enabled but the undistortion (the reference's Python demo on an already debayered
+    image): the chain would be a copy, so the remap reads the caller's frames directly (no chain launch).  rgb8 still needs
+    its channel swap (debayer.cpp:72-73) and keeps the chain.  Resident batch and host frame against the oracle."""
+    import torch
+    w, h = size
+    rng = np.random.default_rng(77)
+    shape = (3, h, w) if encoding == "mono8" else (3, h, w, 3)
+    frames = rng.integers(0, 256, shape, dtype=np.uint8)
+    c = cfg(undistort=True, cam=synth.camera_model(w, h), balance=0.4, fov_scale=0.9)
+    configure(gpu_pipe, c)
+    gpu_pipe.profile_begin(16)
+    out = gpu_pipe.apply_device(torch.from_numpy(frames).cuda(), encoding).cpu().numpy()
+    prof = gpu_pipe.profile_end()
+    assert (prof["chain"][1] == 0) == (encoding != "rgb8"), prof
+    for i in range(3):
+        ref, _ = oracle_run(oracle, c, frames[i], encoding)
+        assert_images_equal(out[i].reshape(ref.shape), ref, "%s direct remap frame %d" % (encoding, i))
+    run_both(gpu_pipe, oracle, c, frames[0], encoding, TOL_INTERP, what="%s undistortion only, host frame" % encoding)
