@@ -596,7 +596,9 @@ def main():
         probe = hbm_probe(pipe, torch)
         # the access shape that bounds each class: the chain is a 1 : 3 expand (non-temporal stores when nothing reads the image
         # again), the remap gathers 3 B and writes 3 B per pixel (12-byte lanes), the statistics pre-pass only reads
-        shape = {"chain": "expand13_nt_GBps" if not pipe.is_undistortion_enabled() else "expand13_GBps", "remap": "copy12_GBps", "stats": "read_GBps"}
+        # (chain inside the remap's tiles: 1 B of Bayer in, 3 B out per pixel -- the expand again)
+        shape = {"chain": "expand13_nt_GBps" if not pipe.is_undistortion_enabled() else "expand13_GBps",
+                 "remap": "expand13_GBps" if FUSED["on"] else "copy12_GBps", "stats": "read_GBps"}
         ceil = probe.get(shape.get(dom, "copy_GBps")) or probe.get("copy_GBps")
         roofline["empirical"] = dict(probe, shape_of_dominant_kernel=shape.get(dom, "copy_GBps"),
                                      frac_of_shape=round(achieved / ceil, 4) if ceil else None,
