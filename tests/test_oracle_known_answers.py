@@ -189,6 +189,16 @@ def test_lab_known_points(oracle):
     assert abs(int(red[0]) - round(53.24 * 2.55)) <= 1 and abs(int(red[1]) - 208) <= 1 and abs(int(red[2]) - 195) <= 1
 
 
+def test_lab_and_hsv_of_the_primaries_equal_the_values_opencv_is_quoted_with(oracle):
+    """The one pin from OUTSIDE this repository that needs no OpenCV at run time: what `cv2.cvtColor` returns for the uint8
+    primaries is quoted all over OpenCV's own tutorials and Q&A sites (py_colorspaces: "green = np.uint8([[[0,255,0]]]) ...
+    [[[ 60 255 255]]]"; COLOR_BGR2LAB of red / green / blue: [136 208 195], [224 42 211], [82 207 20]).  Exact, not +- 1:
+    the 8-bit paths are integer table code (RGB2Lab_b, RGB2HSV_b), so a restatement either has these bytes or is wrong."""
+    px = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0]]], np.uint8)  # BGR: red, green, blue
+    assert oracle.bgr2lab(px)[0].tolist() == [[136, 208, 195], [224, 42, 211], [82, 207, 20]]
+    assert oracle.bgr2hsv(px)[0].tolist() == [[0, 255, 255], [60, 255, 255], [120, 255, 255]]
+
+
 def test_lab_tables_closed_forms(oracle):
     g = oracle.table("srgb_gamma")
     assert g[0] == 0 and g[255] == 2040 and g[10] == round(2040 * (10 / 255) / 12.92)
