@@ -702,7 +702,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     if (pl.wb_mode == rip::WB_SIMPLE) p->d_hist.reserve((size_t)n * 768 * sizeof(unsigned));
   } else if (pl.wb_mode == rip::WB_FLOAT) {
     ensure_ccc(p, pl.mid_rows, pl.mid_cols);
-    p->d_hist.reserve((size_t)n * 65536 * sizeof(unsigned));
+    p->d_hist.reserve((size_t)n * rip::ccc_hist_split(n) * 65536 * sizeof(unsigned));
     p->d_work.reserve((size_t)n * 65536 * 2 * sizeof(float));
     p->d_rowbest.reserve((size_t)n * 256 * 2 * sizeof(float));
     p->d_argmax.reserve((size_t)n * 2 * sizeof(int));
@@ -899,7 +899,8 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
       // setSaturationThreshold(float, float): thresholds are held as float (:437-440); 255 * thr in float
       cp.upper = 255 * (float)p->m.wb_bright_thr;
       cp.lower = 255 * (float)p->m.wb_dark_thr;
-      cp.hist_counts = p->d_hist.as<unsigned>() + (size_t)f0 * 65536;
+      cp.hist_split = rip::ccc_hist_split(n);  // of the whole batch: what d_hist was sized for
+      cp.hist_counts = p->d_hist.as<unsigned>() + (size_t)f0 * cp.hist_split * 65536;
       cp.accum_tab = p->d_accum.as<float>();
       cp.work = p->d_work.as<float>() + (size_t)f0 * 65536 * 2;
       cp.filter_fft = p->d_filter_fft.as<float>();

@@ -346,12 +346,14 @@ __global__ __launch_bounds__(kHistLdsThreads) void ccc_hist_lds_kernel(CccParams
   for (int i = threadIdx.x; i < kHistWords / 4; i += kHistLdsThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);
   if (threadIdx.x == 0) wrapped_bin = -1;
   __syncthreads();
-  const int frame = blockIdx.x;
+  // p.hist_split workgroups per frame, each with its own share of the samples and its own partial histogram (summed by the
+  // row transform that reads them): with one workgroup per frame a batch of 64 frames kept 64 of 256 CUs busy
+  const int frame = (int)blockIdx.x / p.hist_split, part = (int)blockIdx.x - frame * p.hist_split;
   SrcView s{p.src + (size_t)frame * p.src_frame_stride, p.src_step, p.rows, p.cols, p.src_kind, p.bayer_ry, p.bayer_rx};
   // RIP_CCC_UNROLL independent samples per thread and trip, their window loads in flight together (ccc_sample_bins)
   constexpr int kUnroll = RIP_CCC_UNROLL;
   const bool frame_straight = ccc_frame_straight(p, s);
-  for (int i0 = threadIdx.x; i0 < 360 * 270; i0 += kUnroll * kHistLdsThreads) {
+  for (int i0 = threadIdx.x + part * kUnroll * kHistLdsThreads; i0 < 360 * 270; i0 += p.hist_split * kUnroll * kHistLdsThreads) {
     int bin[kUnroll], idx[kUnroll];
     bool live[kUnroll];
 #pragma unroll
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kHistLdsThreads) void ccc_hist_lds_kernel(CccParams
   }
   __syncthreads();
   const int wb = wrapped_bin;
-  uint4* out = reinterpret_cast<uint4*>(p.hist_counts + (size_t)frame * 65536);
+  uint4* out = reinterpret_cast<uint4*>(p.hist_counts + (size_t)blockIdx.x * 65536);
   for (int i = threadIdx.x; i < kHistWords / 2; i += kHistLdsThreads) {  // two words = four bins per store
     const unsigned w0 = words[2 * i], w1 = words[2 * i + 1];
     uint4 o = make_uint4(w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16);
@@ -544,10 +546,12 @@ __global__ __launch_bounds__(256) void ccc_fft_rows16_kernel(CccParams p) {
     twr[t] = p.tabs->tw_re[t];
     twi[t] = p.tabs->tw_im[t];
   }
-  const unsigned int* h = p.hist_counts + (size_t)frame * 65536 + (size_t)row0 * 256;
+  const unsigned int* h = p.hist_counts + (size_t)frame * p.hist_split * 65536 + (size_t)row0 * 256;
   for (int e = t; e < kFftCols * 256; e += 256) {  // e = r * 256 + i: consecutive lanes read consecutive counters
     const int r = e >> 8, i = e & 255;
-    re[r * kFftPitch + bitrev8((unsigned)i)] = p.accum_tab[h[e]];
+    unsigned count = h[e];
+    for (int s = 1; s < p.hist_split; s++) count += h[(size_t)s * 65536 + e];  // partial histograms of the frame (counts: exact)
+    re[r * kFftPitch + bitrev8((unsigned)i)] = p.accum_tab[count];
     im[r * kFftPitch + bitrev8((unsigned)i)] = 0.f;
   }
   __syncthreads();
@@ -698,16 +702,18 @@ bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t str
       }
     }
   }
+  CccParams q = p;
+  q.hist_split = lds_hist ? std::max(1, p.hist_split) : 1;  // the caller's split: its buffer is sized for it
   if (lds_hist) {
-    hipLaunchKernelGGL(ccc_hist_lds_kernel, dim3(p.n_frames), dim3(kHistLdsThreads), lds, stream, p);
+    hipLaunchKernelGGL(ccc_hist_lds_kernel, dim3(p.n_frames * q.hist_split), dim3(kHistLdsThreads), lds, stream, q);
   } else {
     if (hipMemsetAsync(p.hist_counts, 0, (size_t)p.n_frames * 65536 * sizeof(unsigned), stream) != hipSuccess) return false;
-    hipLaunchKernelGGL(ccc_hist_kernel, dim3(kHistBlocks, p.n_frames), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL(ccc_hist_kernel, dim3(kHistBlocks, p.n_frames), dim3(kBlock), 0, stream, q);
   }
   // a histogram that was not launched leaves stale counts behind: stop before anything consumes them (the caller must
   // not advance the Kalman state either)
   if (hipGetLastError() != hipSuccess) return false;
-  hipLaunchKernelGGL(ccc_fft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(ccc_fft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, q);
   hipLaunchKernelGGL(ccc_fft_cols_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(ccc_ifft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(ccc_argmax_kernel, dim3(p.n_frames), dim3(256), 0, stream, p);

@@ -146,7 +146,8 @@ struct CccParams {
   int n_frames;
   CccGeom geom;
   float upper, lower;            // 255*bright_thr, 255*dark_thr
-  unsigned int* hist_counts;     // [n_frames][65536], zeroed
+  unsigned int* hist_counts;     // [n_frames][hist_split][65536]; zeroed by the caller of the atomic kernel
+  int hist_split;                // partial histograms per frame the LDS-histogram kernel writes (ccc_hist_split of the batch the buffer was sized for)
   const float* accum_tab;        // [97201]
   float* work;                   // [n_frames][65536] complex
   const float* filter_fft;       // [65536] complex
@@ -246,6 +247,9 @@ void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream);
 // Returns false when the histogram launch failed: nothing after it was enqueued and the caller must not run the
 // state-advancing finalisation on stale data.
 bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t stream);
+// Partial histograms per frame the LDS-histogram kernel may write for a batch of n frames (one 1024-thread workgroup each:
+// fewer than 128 frames would leave most CUs idle with one workgroup per frame); the histogram buffer holds n * this * 65536 counters.
+inline int ccc_hist_split(int n_frames) { return n_frames >= 192 ? 1 : (n_frames >= 96 ? 2 : 4); }
 // rip_probe.hip: one launch of a streaming microbenchmark (rip_debug_hbm_probe); returns the bytes it moves, 0 = unknown kind
 size_t launch_hbm_probe(int kind, const void* src, void* dst, size_t bytes, hipStream_t stream);
 // Turns raw statistics into FrameWb (grey-world / pca) or runs the ccc temporal filter + gains.
