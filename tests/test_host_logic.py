@@ -285,3 +285,19 @@ def test_debug_dump_normalisation_and_png_writer(host_pipe, tmp_path):
     assert np.array_equal(read_png(path), grey)
     with pytest.raises(RipIOError):
         host_pipe.debug_write_png(str(tmp_path / "no_such_dir" / "x.png"), grey)
+
+
+def test_bench_without_a_gpu_exits_loudly_and_prints_no_line():
+    """bench.py on a host without an MI355X (this container): non-zero exit, a message, no JSON line -- whatever --gpus says.
+    (The product path has no CPU execution; a silent number from anything else would be worse than none.)"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for gpus in ("1", "2"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", gpus, "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "MI355X" in r.stderr
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
