@@ -709,7 +709,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   }
   uint8_t* chain_dst = d_out;
   size_t chain_step = out_step, chain_stride = out_frame_stride;
-  bool tiled = false, fused = false, direct = false;
+  bool tiled = false, fused = false, direct = false, mono_direct = false;
   // the remap's view of one group of frames: plan, destination, and -- `src` -- either the intermediate image or, on the
   // fused path, the Bayer frames themselves
   auto tiled_params = [&](const uint8_t* src, size_t src_step, size_t src_frame_stride, int src_rows, int src_cols, int f0, int ng) {
@@ -735,6 +735,11 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     tp.border_list = p->d_plan_border.as<uint32_t>();
     tp.n_border = p->plan_n_border;
     tp.lds_bytes = (unsigned)p->plan.max_lds_bytes;
+    return tp;
+  };
+  auto mono_ops = [&](rip::RemapTiledParams tp) {
+    tp.mono_lut = (pl.stage_bits & rip::ST_GAMMA) ? p->d_tabs.as<uint8_t>() + offsetof(rip::DevTables, gamma_lut) : nullptr;
+    tp.mono_flip180 = pl.flip_angle == 180 ? 1 : 0;
     return tp;
   };
   // the chain's parameters for one group of frames (dst / taps filled in by the caller)
@@ -782,6 +787,13 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     // chain would be a copy -- the remap gathers from the caller's frames as they lie
     direct = !fused && !d_tap_col && !d_tap_deb && (pl.src_kind == rip::SRC_BGR || pl.src_kind == rip::SRC_MONO) && pl.flip_angle == 0 &&
              pl.wb_mode == rip::WB_NONE && pl.stage_bits == 0;
+    // mono8: the whole chain is a 180-degree flip and the gamma table -- the ring kernel addresses the mirrored rectangle
+    // and maps the taps through the table as it gathers them
+    if (!direct && !fused && tiled && !d_tap_col && !d_tap_deb && pl.src_kind == rip::SRC_MONO && (pl.flip_angle == 0 || pl.flip_angle == 180) &&
+        p->tn.remap_fused) {
+      rip::RemapTiledParams tp = mono_ops(tiled_params(d_in, in_step, in_frame_stride, rows, cols, 0, n));
+      direct = mono_direct = rip::launch_remap_tiled(tp, p->tn, p->stream, /*dry_run=*/true);
+    }
     if (fused || direct) {
     } else if (d_tap_col) {  // the pre-undistortion image is an API output: write it once, gather from it
       chain_dst = d_tap_col;
@@ -931,6 +943,10 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     if (direct) {  // no chain at all: the remap below reads the input frames
       ProfScope ps(p, RIP_KERNEL_REMAP, front);
       rip::RemapTiledParams tp = tiled_params(in_g, in_step, in_frame_stride, rows, cols, f0, ng);
+      if (mono_direct) {
+        if (!rip::launch_remap_tiled(mono_ops(tp), p->tn, front)) throw DeviceError("internal: the ring remap refused a geometry it had accepted");
+        continue;
+      }
       if (!(tiled && rip::launch_remap_tiled(tp, p->tn, front)) && !rip::launch_remap(tp.base, front))
         throw InvalidArgument("undistortion: frame geometry exceeds the kernels' 32-bit addressing");
       continue;

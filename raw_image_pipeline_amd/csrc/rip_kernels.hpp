@@ -184,6 +184,10 @@ struct RemapTiledParams {
   unsigned lds_bytes;          // dynamic LDS per staging buffer (>= max over tiles)
   int double_buffer;           // set by the launcher: two staging buffers, loads of frame f+1 overlap the gather of f
   int stages;                  // set by the launcher (ring kernel): LDS ring size, prefetch distance = stages - 1
+  // one-channel frames gathered straight from the caller's frames (ring kernel only): the taps go through this 256-byte
+  // table (the gamma LUT; null = none) and / or are addressed in the 180-degree-flipped frame -- the whole mono8 chain
+  const uint8_t* mono_lut;
+  int mono_flip180;
 };
 
 // Fisheye maps on the device (rip_maps.hip): iR = (P R)^-1 from the host, K / D of the distorted camera.
@@ -233,7 +237,8 @@ Tunables tunables_from_env();  // rip_api.cpp; called by rip_create
 
 // ---- launchers (asynchronous on `stream`) -------------------------------------------------------
 // Returns false (and launches nothing) when the geometry does not qualify for the tiled kernel.
-bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream);
+// dry_run: only answer (the API decides with it whether a mono8 chain can be folded into the gather).
+bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream, bool dry_run = false);
 // rip_fused.hip: debayer + memory-rate stages + remap in one kernel over the Bayer frames (p.base.src); false when the
 // configuration / geometry does not qualify (nothing launched).  dry_run: only answer.
 bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max_rect_w, int max_rect_h, const Tunables& tn, hipStream_t stream,

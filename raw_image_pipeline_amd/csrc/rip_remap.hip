@@ -46,6 +46,29 @@ __global__ __launch_bounds__(kBlock) void remap_border_kernel(RemapTiledParams p
   const float2 m = reinterpret_cast<const float2*>(b.map_xy)[__umul24((unsigned)yd, (unsigned)b.dcols) + (unsigned)xd];
   const int frame = blockIdx.y;
   const RemapSrc s = remap_src(b, frame);
+  if (b.channels == 1 && (p.mono_lut || p.mono_flip180)) {  // uniform: the taps are pixels of the flipped, table-mapped frame
+    const int sxq = round_map(m.x), syq = round_map(m.y);
+    const int sx = clampi(sxq >> 5, -32768, 32767), sy = clampi(syq >> 5, -32768, 32767);
+    const int fx = sxq & 31, fy = syq & 31;
+    const int wx[2] = {32 - fx, fx}, wy[2] = {32 - fy, fy};
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int rowsum = 0;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int y = sy + j, x = sx + k;
+        if (y < 0 || y >= b.rows || x < 0 || x >= b.cols) continue;  // border constant 0
+        const int ys = p.mono_flip180 ? b.rows - 1 - y : y, xs = p.mono_flip180 ? b.cols - 1 - x : x;
+        int v = s.frame[__umul24((unsigned)ys, s.step) + (unsigned)xs];
+        if (p.mono_lut) v = p.mono_lut[v];
+        rowsum += mul24(v, wx[k]);
+      }
+      acc += mul24(rowsum, wy[j]);
+    }
+    b.dst[(size_t)frame * b.dst_frame_stride + (__umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd)] = (uint8_t)((acc + 512) >> 10);
+    return;
+  }
   if (b.channels == 1) {  // uniform
     int q[1];
     remap_pixel<1>(s, m.x, m.y, q);
@@ -194,9 +217,19 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_tiled_kernel(RemapTil
 
 // CN: channels of the image (3: interleaved BGR; 1: mono8 frames, which the reference passes through flip, gamma and
 // undistortion unchanged in layout).  The plan -- source rectangles in pixels, 1/32-px tap words -- does not depend on it.
-template <int PRE, int CN>
+// LUT (CN == 1 only): the taps go through p.mono_lut, i.e. the gather reads the gamma-corrected frame without it ever being
+// written; p.mono_flip180 (CN == 1, either LUT): the staged rectangle is the mirrored one of the caller's frame and the four
+// taps of a pixel are addressed from its far corner, weights swapped -- the sums are the same integers in another order.
+template <int PRE, int CN, bool LUT = false>
 __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  __shared__ uint8_t s_lut[LUT ? 256 : 4];
+  static_assert(!LUT || (CN == 1 && kRemapTileThreads == 256), "the table pass is the mono8 chain");
+  if constexpr (LUT) {
+    s_lut[threadIdx.x] = p.mono_lut[threadIdx.x];
+    __syncthreads();
+  }
+  const bool flip = CN == 1 && p.mono_flip180 != 0;
   constexpr unsigned kStage = (unsigned)PRE * kRemapTileThreads * 16u;  // bytes per stage
   const RemapParams& b = p.base;
   const int ntiles = p.tiles_x * p.tiles_y;
@@ -221,7 +254,9 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
     const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
     const int yd = ty * kRemapTileH + lrow, xd = tx * kRemapTileW + lgrp * 4;
     const bool in_image = yd < b.drows && xd < b.dcols;
-    const unsigned xbyte0 = (unsigned)d.x0 * (unsigned)CN;
+    // origin of the staged rectangle in the frame the kernel reads (the plan's rectangle, mirrored for flip)
+    const int ox = flip ? b.cols - d.x0 - d.w : d.x0, oy = flip ? b.rows - d.y0 - d.h : d.y0;
+    const unsigned xbyte0 = (unsigned)ox * (unsigned)CN;
     const unsigned chunk0 = xbyte0 & ~15u, ph = xbyte0 & 15u;
     const unsigned pitch = (ph + (unsigned)d.w * (unsigned)CN + 15u) & ~15u;  // rip_host.cpp remap_tile_lds_bytes (CN == 3)
     const unsigned chunks = pitch >> 4;
@@ -236,7 +271,7 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
       const unsigned i = (unsigned)tid + (unsigned)j * kRemapTileThreads;
       int r, c;
       cm.split((int)i, r, c);
-      goff[j] = i < total ? __umul24((unsigned)(d.y0 + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFF0u;
+      goff[j] = i < total ? __umul24((unsigned)(oy + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFF0u;
     }
     unsigned tap_addr[4], wxb[4], wyy[4];
 #pragma unroll
@@ -244,9 +279,15 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
       const uint32_t w = words[k];
       const bool live = w < kPlanBorder;
       const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u, fy = w >> 27;
-      tap_addr[k] = live ? __umul24(rely, pitch) + relx * (unsigned)CN + ph : 0u;
-      wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
-      wyy[k] = (32u - fy) | (fy << 16);
+      if (flip) {  // the dword at (h-2-rely, w-2-relx) of the mirrored rectangle holds the taps (x+1, x) of row y+1; the row below it is y
+        tap_addr[k] = live ? __umul24((unsigned)d.h - 2u - rely, pitch) + ((unsigned)d.w - 2u - relx) + ph : 0u;
+        wxb[k] = live ? fx | ((32u - fx) << 24) : 0u;
+        wyy[k] = fy | ((32u - fy) << 16);
+      } else {
+        tap_addr[k] = live ? __umul24(rely, pitch) + relx * (unsigned)CN + ph : 0u;
+        wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
+        wyy[k] = (32u - fy) | (fy << 16);
+      }
     }
     const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * (unsigned)CN;
 
@@ -265,7 +306,11 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const uint32_t tl = lds_load4(buf, tap_addr[k]), bl = lds_load4(buf, tap_addr[k] + pitch);
+          uint32_t tl = lds_load4(buf, tap_addr[k]), bl = lds_load4(buf, tap_addr[k] + pitch);
+          if constexpr (LUT) {
+            tl = (uint32_t)s_lut[tl & 0xffu] | ((uint32_t)s_lut[(tl >> 8) & 0xffu] << 8);
+            bl = (uint32_t)s_lut[bl & 0xffu] | ((uint32_t)s_lut[(bl >> 8) & 0xffu] << 8);
+          }
           const unsigned wy0 = wyy[k] & 0xffffu, wy1 = wyy[k] >> 16;
           const unsigned w2 = (wxb[k] & 0xffu) | ((wxb[k] >> 16) & 0xff00u);
           const unsigned top = __builtin_amdgcn_udot4(tl, w2, 16u, false);
@@ -349,9 +394,10 @@ __global__ __launch_bounds__(kBlock) void remap_generic_kernel(RemapParams p) {
 
 }  // namespace
 
-bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream) {
+bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream, bool dry_run) {
   const RemapParams& b = p.base;
   if (b.n_frames <= 0) return true;
+  if ((p.mono_lut || p.mono_flip180) && b.channels != 1) return false;
   const bool ok = (b.channels == 3 || b.channels == 1) && b.dcols % 4 == 0 && b.dst_step % 4 == 0 && b.dst_frame_stride % 4 == 0 && aligned4(b.dst) &&
                   b.src_step % 16 == 0 && b.src_frame_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(b.src) & 15u) == 0 &&
                   (reinterpret_cast<uintptr_t>(p.words) & 15u) == 0 && b.src_step < (1u << 24) && b.rows < (1 << 23) &&
@@ -371,6 +417,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
   // one-channel frames run the ring kernel only (PRE chosen from the three-channel footprint of the plan: an upper bound of
   // the one-channel one, the surplus lanes load from an out-of-range offset, i.e. nothing)
   if (b.channels == 1 && !(ring_env && chunks <= 4u * kRemapTileThreads)) return false;
+  if (dry_run) return true;
   if (ring_env && chunks <= 4u * kRemapTileThreads) {
     // LDS-DMA ring: PRE chunks per lane and frame, `stages` buffers of PRE * 4 KiB
     const int pre = chunks <= 1u * kRemapTileThreads ? 1 : (chunks <= 2u * kRemapTileThreads ? 2 : 4);
@@ -396,7 +443,14 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
     int groups = std::max((256 * per_cu) / blocks, (b.n_frames + frames_per_visit - 1) / frames_per_visit);
     groups = std::max(1, std::min(b.n_frames, groups));
     const dim3 grid(blocks, groups);
-    if (b.channels == 1) {
+    if (b.channels == 1 && q.mono_lut) {
+      if (pre == 1)
+        hipLaunchKernelGGL((remap_ring_kernel<1, 1, true>), grid, dim3(kRemapTileThreads), lds, stream, q);
+      else if (pre == 2)
+        hipLaunchKernelGGL((remap_ring_kernel<2, 1, true>), grid, dim3(kRemapTileThreads), lds, stream, q);
+      else
+        hipLaunchKernelGGL((remap_ring_kernel<4, 1, true>), grid, dim3(kRemapTileThreads), lds, stream, q);
+    } else if (b.channels == 1) {
       if (pre == 1)
         hipLaunchKernelGGL((remap_ring_kernel<1, 1>), grid, dim3(kRemapTileThreads), lds, stream, q);
       else if (pre == 2)

@@ -784,7 +784,7 @@ def test_submit_reads_a_pageable_5_MB_frame_before_it_returns(rip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [(64, 48), (132, 36), (640, 480), (2448, 2048)])
+@pytest.mark.parametrize("size", [(64, 48), (132, 36), (640, 480), (1008, 502), (2448, 2048)])
 @pytest.mark.parametrize("angle,gamma,undistort", [(0, False, False), (180, True, False), (0, True, True), (180, False, True), (180, True, True)])
 def test_mono8_fast_path_flip_gamma_undistortion(gpu_pipe, oracle, size, angle, gamma, undistort):
     """mono8 frames (the reference passes single-channel images through flip, the gamma LUT and undistortion; every colour

@@ -14,9 +14,12 @@ import torch  # noqa: E402
 from raw_image_pipeline_amd import RawImagePipeline, synth  # noqa: E402
 
 BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ONLY = os.environ.get("PATH_SURVEY_ONLY", "")  # substring filter of the path names
 
 
 def measure(name, pipe, frames, enc, steps=6):
+    if ONLY and ONLY not in name:
+        return
     pipe.set_stream(torch.cuda.current_stream())
     out = pipe.apply_device(frames, enc)
     pipe.apply_device(frames, enc, out=out)
