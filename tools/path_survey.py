@@ -70,6 +70,10 @@ def main():
     bgr = torch.from_numpy(np.stack([synth.gen_scene_bgr(w, h, seed=2)] * BATCH)).cuda()
     for enc in ("bgr8", "rgb8"):
         measure("colour input %s, full chain + remap" % enc, full(w, h), bgr, enc)
+    for enc in ("bgr8", "rgb8"):  # the memory-rate stage set (grey-world gains, colour matrix, gamma): chain inside the remap's tiles
+        p = full(w, h)
+        p.set_vignetting_correction(False)
+        measure("colour input %s, no vignetting, + remap" % enc, p, bgr, enc)
     p = RawImagePipeline(False, "", "", "", device=0)
     p.set_flip(True)
     p.set_flip_angle(180)
