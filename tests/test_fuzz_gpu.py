@@ -79,6 +79,16 @@ def test_random_configuration_on_colour_and_mono_input(gpu_pipe, oracle, seed):
     got = gpu_pipe.process(img, encoding)
     ref, _ = oracle_run(oracle, c, img, encoding)
     assert_images_equal(got, ref.reshape(got.shape), what)
+    if seed % 2 == 0:  # resident batch, no tap: the paths that skip the chain (remap straight from the caller's frames; mono8 flip + table in the gather)
+        import torch
+        n = int(rng.integers(2, 6))
+        frames = np.stack([img] + [rng.integers(0, 256, img.shape, dtype=np.uint8) for _ in range(n - 1)])
+        out = gpu_pipe.apply_device(torch.from_numpy(frames).cuda(), encoding)
+        torch.cuda.synchronize()
+        out = out.cpu().numpy()
+        for i in range(n):
+            ref, _ = oracle_run(oracle, c, frames[i], encoding)
+            assert_images_equal(out[i].reshape(ref.shape), ref, what + " batch frame %d/%d" % (i, n))
 
 
 @pytest.mark.parametrize("seed", range(max(1, N_BAYER // 3)))
