@@ -500,7 +500,9 @@ def main():
                                               "lds_frac": round(items_per_s * led["lds_cycles_per_item"] * 4 / peak, 4),
                                               "source": "profiles/chain_ledger.json (tools/chain_ledger.py)"},
                                     "measured_frac": None, "measured": None, "peak_instr_per_simd_cycle": 0.5}
-                roofline["bound"] = "valu+lds"
+                # `bound` stays "hbm": it names the roofline `peak` / `frac` are priced against (the contract's two values are
+                # "hbm" and "mfma").  What actually limits this kernel goes into `limiter`, with `valu_floor_frac` as its ceiling.
+                roofline["limiter"] = "valu+lds"
         except Exception:
             pass
 
