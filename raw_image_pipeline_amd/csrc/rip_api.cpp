@@ -221,6 +221,10 @@ struct rip_pipeline {
   // prefix of d_stats known to hold zeroed FrameStats records (the grey-world / pca statistics kernels clean up after themselves)
   const void* stats_clean_ptr = nullptr;
   size_t stats_clean_cap = 0, stats_clean_bytes = 0;  // (pointer, capacity) identify the allocation: DevBuf only ever grows
+  // the leading bytes of d_hist known to be zero: the ccc estimator's global-atomic histogram (small batches) hands its
+  // counters back zeroed, so a stream of single frames pays for one memset, not one per frame
+  const void* hist_clean_ptr = nullptr;
+  size_t hist_clean_cap = 0, hist_clean_bytes = 0;
   // cross-kernel overlap inside one batch (run_batch): the remap of frame group g runs on this internal stream while the
   // statistics and the fused chain of group g + 1 run on the caller's stream
   hipStream_t aux_stream = nullptr;
@@ -853,6 +857,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     } else if (sums) {
       rip::FrameStats* stats_g = p->d_stats.as<rip::FrameStats>() + f0;
       unsigned* hist_g = pl.wb_mode == rip::WB_SIMPLE ? p->d_hist.as<unsigned>() + (size_t)f0 * 768 : nullptr;
+      if (hist_g) p->hist_clean_bytes = 0;  // the same buffer serves SimpleWB's histograms
       // grey-world / pca: the statistics kernel itself finishes a frame (gains written by the workgroup that ends last) and
       // hands its FrameStats back zeroed, so neither a memset nor a finalisation launch separates the batches -- two
       // dependent launches less on the single-frame path.  The records are cleared here only when they are not known to be
@@ -920,14 +925,25 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
       cp.row_best = p->d_rowbest.as<float>() + (size_t)f0 * 256 * 2;
       cp.argmax = p->d_argmax.as<int>() + (size_t)f0 * 2;
       cp.tabs = p->d_tabs.as<rip::DevTables>();
+      const size_t hist_bytes = (size_t)ng * 65536 * sizeof(unsigned);  // what the global-atomic kernel accumulates into
+      cp.hist_is_clean = (groups == 1 && p->hist_clean_ptr == p->d_hist.ptr && p->hist_clean_cap == p->d_hist.cap && p->hist_clean_bytes >= hist_bytes) ? 1 : 0;
+      p->hist_clean_bytes = 0;  // until the estimator has been enqueued completely
       bool estimated;
+      int left_clean = 0;
       {
         ProfScope ps(p, RIP_KERNEL_CCC, front);
-        estimated = rip::launch_ccc_estimate(cp, p->tn, front);
+        estimated = rip::launch_ccc_estimate(cp, p->tn, front, &left_clean);
       }
       // no histogram, no estimate: fail before the finalisation advances the persistent Kalman state on stale data
       if (!estimated) throw DeviceError("ccc white balance: a kernel of the estimator could not be launched");
-      rip::launch_wb_finalize(rip::WB_FLOAT, nullptr, cp.argmax, p->d_ccc_state.as<rip::CccState>(), cp.tabs, wb_g, ng, front);
+      if (left_clean && groups == 1) {
+        p->hist_clean_ptr = p->d_hist.ptr;
+        p->hist_clean_cap = p->d_hist.cap;
+        p->hist_clean_bytes = hist_bytes;
+      }
+      const bool inline_argmax = rip::ccc_argmax_in_finalize(ng);
+      rip::launch_wb_finalize(rip::WB_FLOAT, nullptr, cp.argmax, p->d_ccc_state.as<rip::CccState>(), cp.tabs, wb_g, ng, front, nullptr, 0.f, 0,
+                              inline_argmax ? cp.row_best : nullptr, inline_argmax ? cp.argmax : nullptr);
     }
 
     // ---- chain + remap in one kernel (memory-rate stage sets, no taps) ---------------------------------

@@ -298,8 +298,12 @@ __device__ __forceinline__ void ccc_sample_bins(const CccParams& p, const CccSam
 }
 
 // Small batches: kHistBlocks workgroups per frame, one global atomic per sample into a zeroed histogram (a frame's
-// samples spread over the chip: lowest latency for a single frame).
-constexpr int kHistBlocks = 24;
+// samples spread over the chip: lowest latency for a single frame; one resident 1440 x 1080 frame, kernel run time with
+// 24 / 96 / 190 workgroups: 17.7 / 11.1 / 9.8 us -- 190 is one trip per lane, but the whole call is no shorter than with 96).
+#ifndef RIP_CCC_HIST_BLOCKS
+#define RIP_CCC_HIST_BLOCKS 96
+#endif
+constexpr int kHistBlocks = RIP_CCC_HIST_BLOCKS;
 __global__ __launch_bounds__(kBlock) void ccc_hist_kernel(CccParams p) {
   __shared__ CccSampleTabs tb;
   tb.load<kBlock>(p);
@@ -419,6 +423,10 @@ __device__ __forceinline__ void fft256_lds(float* re, float* im, const float* tw
 // loads of the work buffer, of the filter / bias spectra and the stores move whole lines (one column per
 // workgroup touched 8 bytes of every line: 1.9 GB of traffic for 0.27 GB of data, PMC).  The butterflies of a
 // column are evaluated exactly as fft256_lds does, so the response is unchanged bit for bit.
+#ifndef RIP_CCC_FFT_FEW
+#define RIP_CCC_FFT_FEW 4
+#endif
+constexpr int kFftFewFrames = RIP_CCC_FFT_FEW;  // batches up to this size run the transforms four columns per one-wave workgroup
 constexpr int kFftCols = 16, kFftPitch = 257;  // odd pitch: the 16 columns of one element fall into 16 banks
 
 // 256-point FFTs of kFftCols columns held as re/im[c * kFftPitch + i] (bit-reversed input on entry, after a barrier;
@@ -439,8 +447,11 @@ __device__ __forceinline__ void fft_bfly(float& ur, float& ui, float& xr, float&
   xi = hi;
 }
 
+// COLS columns on 16 * COLS threads: 16 for batches (a row of the slab is one 128-byte line), 4 -- one wave per workgroup,
+// 64 workgroups per frame -- for the few frames of a latency-bound call; the butterflies and their order are the same.
+template <int COLS>
 __device__ __forceinline__ void fft256_columns_lds(float* re, float* im, const float* twr, const float* twi, bool inverse) {
-  const int c = threadIdx.x & (kFftCols - 1), g = threadIdx.x >> 4;
+  const int c = threadIdx.x & (COLS - 1), g = threadIdx.x / COLS;
   float* cre = re + c * kFftPitch;
   float* cim = im + c * kFftPitch;
   auto tw = [&](int idx, float& wr, float& wi) {
@@ -539,47 +550,52 @@ __device__ __forceinline__ void fft256_columns_lds(float* re, float* im, const f
 // Row transforms, kFftCols rows per 256-thread workgroup on the same slab code (a row is 1 KB of contiguous floats, so
 // the loads and stores are whole lines as well).  One row per 128-thread workgroup (eight barriers per transform, two waves)
 // was latency-bound: 0.20 ms of the estimator's 0.77 ms per 256 frames.
-__global__ __launch_bounds__(256) void ccc_fft_rows16_kernel(CccParams p) {
-  __shared__ float re[kFftCols * kFftPitch], im[kFftCols * kFftPitch], twr[128], twi[128];
-  const int row0 = blockIdx.x * kFftCols, frame = blockIdx.y, t = threadIdx.x;
-  if (t < 128) {
-    twr[t] = p.tabs->tw_re[t];
-    twi[t] = p.tabs->tw_im[t];
+template <int COLS>
+__global__ __launch_bounds__(16 * COLS) void ccc_fft_rows16_kernel(CccParams p) {
+  __shared__ float re[COLS * kFftPitch], im[COLS * kFftPitch], twr[128], twi[128];
+  const int row0 = blockIdx.x * COLS, frame = blockIdx.y, t = threadIdx.x;
+  for (int i = t; i < 128; i += 16 * COLS) {
+    twr[i] = p.tabs->tw_re[i];
+    twi[i] = p.tabs->tw_im[i];
   }
-  const unsigned int* h = p.hist_counts + (size_t)frame * p.hist_split * 65536 + (size_t)row0 * 256;
-  for (int e = t; e < kFftCols * 256; e += 256) {  // e = r * 256 + i: consecutive lanes read consecutive counters
+  unsigned int* h = p.hist_counts + (size_t)frame * p.hist_split * 65536 + (size_t)row0 * 256;
+  for (int e = t; e < COLS * 256; e += 16 * COLS) {  // e = r * 256 + i: consecutive lanes read consecutive counters
     const int r = e >> 8, i = e & 255;
     unsigned count = h[e];
+    // the global-atomic kernel accumulates into zeroed counters: the only reader hands them back zeroed, so the next
+    // frame needs no memset (one dependent operation less per frame)
+    if (p.hist_zero_after) h[e] = 0u;  // every counter, coalesced: a store only where the count is non-zero runs 1 us longer
     for (int s = 1; s < p.hist_split; s++) count += h[(size_t)s * 65536 + e];  // partial histograms of the frame (counts: exact)
     re[r * kFftPitch + bitrev8((unsigned)i)] = p.accum_tab[count];
     im[r * kFftPitch + bitrev8((unsigned)i)] = 0.f;
   }
   __syncthreads();
-  fft256_columns_lds(re, im, twr, twi, false);
+  fft256_columns_lds<COLS>(re, im, twr, twi, false);
   float2* out = reinterpret_cast<float2*>(p.work) + (size_t)frame * 65536 + (size_t)row0 * 256;
-  for (int e = t; e < kFftCols * 256; e += 256) {
+  for (int e = t; e < COLS * 256; e += 16 * COLS) {
     const int r = e >> 8, i = e & 255;
     out[e] = make_float2(re[r * kFftPitch + i], im[r * kFftPitch + i]);
   }
 }
 
 // inverse FFT of kFftCols rows; per-row first maximum of the real part
-__global__ __launch_bounds__(256) void ccc_ifft_rows16_kernel(CccParams p) {
-  __shared__ float re[kFftCols * kFftPitch], im[kFftCols * kFftPitch], twr[128], twi[128];
-  const int row0 = blockIdx.x * kFftCols, frame = blockIdx.y, t = threadIdx.x;
-  if (t < 128) {
-    twr[t] = p.tabs->tw_re[t];
-    twi[t] = p.tabs->tw_im[t];
+template <int COLS>
+__global__ __launch_bounds__(16 * COLS) void ccc_ifft_rows16_kernel(CccParams p) {
+  __shared__ float re[COLS * kFftPitch], im[COLS * kFftPitch], twr[128], twi[128];
+  const int row0 = blockIdx.x * COLS, frame = blockIdx.y, t = threadIdx.x;
+  for (int i = t; i < 128; i += 16 * COLS) {
+    twr[i] = p.tabs->tw_re[i];
+    twi[i] = p.tabs->tw_im[i];
   }
   const float2* in = reinterpret_cast<const float2*>(p.work) + (size_t)frame * 65536 + (size_t)row0 * 256;
-  for (int e = t; e < kFftCols * 256; e += 256) {
+  for (int e = t; e < COLS * 256; e += 16 * COLS) {
     const int r = e >> 8, i = e & 255;
     const float2 v = in[e];
     re[r * kFftPitch + bitrev8((unsigned)i)] = v.x;
     im[r * kFftPitch + bitrev8((unsigned)i)] = v.y;
   }
   __syncthreads();
-  fft256_columns_lds(re, im, twr, twi, true);
+  fft256_columns_lds<COLS>(re, im, twr, twi, true);
   // first maximum of each row: 16 lanes per row, each scans 16 consecutive columns in order, then a 16-lane min-index
   // reduction with the same tie rule (larger value, else smaller column)
   const int r = t >> 4, l = t & 15;
@@ -606,13 +622,14 @@ __global__ __launch_bounds__(256) void ccc_ifft_rows16_kernel(CccParams p) {
   }
 }
 
-__global__ __launch_bounds__(256) void ccc_fft_cols_kernel(CccParams p) {
-  __shared__ float re[kFftCols * kFftPitch], im[kFftCols * kFftPitch], twr[128], twi[128];
-  const int col0 = blockIdx.x * kFftCols, frame = blockIdx.y, t = threadIdx.x;
-  const int c = t & (kFftCols - 1), r0 = t >> 4;  // this thread moves rows r0, r0 + 16, ... of column col0 + c
-  if (t < 128) {
-    twr[t] = p.tabs->tw_re[t];
-    twi[t] = p.tabs->tw_im[t];
+template <int COLS>
+__global__ __launch_bounds__(16 * COLS) void ccc_fft_cols_kernel(CccParams p) {
+  __shared__ float re[COLS * kFftPitch], im[COLS * kFftPitch], twr[128], twi[128];
+  const int col0 = blockIdx.x * COLS, frame = blockIdx.y, t = threadIdx.x;
+  const int c = t & (COLS - 1), r0 = t / COLS;  // this thread moves rows r0, r0 + 16, ... of column col0 + c
+  for (int i = t; i < 128; i += 16 * COLS) {
+    twr[i] = p.tabs->tw_re[i];
+    twi[i] = p.tabs->tw_im[i];
   }
   float2* data = reinterpret_cast<float2*>(p.work) + (size_t)frame * 65536 + col0 + c;
 #pragma unroll 4
@@ -623,7 +640,7 @@ __global__ __launch_bounds__(256) void ccc_fft_cols_kernel(CccParams p) {
     im[c * kFftPitch + j] = v.y;
   }
   __syncthreads();
-  fft256_columns_lds(re, im, twr, twi, false);
+  fft256_columns_lds<COLS>(re, im, twr, twi, false);
   const float2* F = reinterpret_cast<const float2*>(p.filter_fft) + col0 + c;
   const float2* B = reinterpret_cast<const float2*>(p.bias_fft) + col0 + c;
   float qr[16], qi[16];
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(256) void ccc_fft_cols_kernel(CccParams p) {
     im[c * kFftPitch + j] = qi[m];
   }
   __syncthreads();
-  fft256_columns_lds(re, im, twr, twi, true);
+  fft256_columns_lds<COLS>(re, im, twr, twi, true);
 #pragma unroll 4
   for (int i = r0; i < 256; i += 16) data[(size_t)i * 256] = make_float2(re[c * kFftPitch + i], im[c * kFftPitch + i]);
 }
@@ -678,7 +695,8 @@ __global__ __launch_bounds__(256) void ccc_argmax_kernel(CccParams p) {
 
 }  // namespace
 
-bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t stream) {
+bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t stream, int* hist_left_clean) {
+  if (hist_left_clean) *hist_left_clean = 0;
   if (p.n_frames <= 0) return true;
   // Batches of at least tn.ccc_lds_hist_min frames take the LDS histogram (one workgroup = one CU per frame).  It needs
   // ~135 KB of dynamic LDS, an opt-in above 64 KB that is per device (a process that drives several GPUs needs it on each);
@@ -704,20 +722,29 @@ bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t str
   }
   CccParams q = p;
   q.hist_split = lds_hist ? std::max(1, p.hist_split) : 1;  // the caller's split: its buffer is sized for it
+  q.hist_zero_after = lds_hist ? 0 : 1;
   if (lds_hist) {
     hipLaunchKernelGGL(ccc_hist_lds_kernel, dim3(p.n_frames * q.hist_split), dim3(kHistLdsThreads), lds, stream, q);
   } else {
-    if (hipMemsetAsync(p.hist_counts, 0, (size_t)p.n_frames * 65536 * sizeof(unsigned), stream) != hipSuccess) return false;
+    if (!p.hist_is_clean && hipMemsetAsync(p.hist_counts, 0, (size_t)p.n_frames * 65536 * sizeof(unsigned), stream) != hipSuccess) return false;
     hipLaunchKernelGGL(ccc_hist_kernel, dim3(kHistBlocks, p.n_frames), dim3(kBlock), 0, stream, q);
   }
   // a histogram that was not launched leaves stale counts behind: stop before anything consumes them (the caller must
   // not advance the Kalman state either)
   if (hipGetLastError() != hipSuccess) return false;
-  hipLaunchKernelGGL(ccc_fft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, q);
-  hipLaunchKernelGGL(ccc_fft_cols_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
-  hipLaunchKernelGGL(ccc_ifft_rows16_kernel, dim3(256 / kFftCols, p.n_frames), dim3(256), 0, stream, p);
-  hipLaunchKernelGGL(ccc_argmax_kernel, dim3(p.n_frames), dim3(256), 0, stream, p);
-  return hipGetLastError() == hipSuccess;
+  if (p.n_frames <= kFftFewFrames) {  // a few frames: 64 one-wave workgroups per frame instead of 16 four-wave ones
+    hipLaunchKernelGGL(ccc_fft_rows16_kernel<4>, dim3(64, p.n_frames), dim3(64), 0, stream, q);
+    hipLaunchKernelGGL(ccc_fft_cols_kernel<4>, dim3(64, p.n_frames), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(ccc_ifft_rows16_kernel<4>, dim3(64, p.n_frames), dim3(64), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(ccc_fft_rows16_kernel<kFftCols>, dim3(256 / kFftCols, p.n_frames), dim3(16 * kFftCols), 0, stream, q);
+    hipLaunchKernelGGL(ccc_fft_cols_kernel<kFftCols>, dim3(256 / kFftCols, p.n_frames), dim3(16 * kFftCols), 0, stream, p);
+    hipLaunchKernelGGL(ccc_ifft_rows16_kernel<kFftCols>, dim3(256 / kFftCols, p.n_frames), dim3(16 * kFftCols), 0, stream, p);
+  }
+  if (!ccc_argmax_in_finalize(p.n_frames)) hipLaunchKernelGGL(ccc_argmax_kernel, dim3(p.n_frames), dim3(256), 0, stream, p);
+  const bool ok = hipGetLastError() == hipSuccess;
+  if (ok && !lds_hist && hist_left_clean) *hist_left_clean = 1;
+  return ok;
 }
 
 }  // namespace rip

@@ -146,7 +146,9 @@ struct CccParams {
   int n_frames;
   CccGeom geom;
   float upper, lower;            // 255*bright_thr, 255*dark_thr
-  unsigned int* hist_counts;     // [n_frames][hist_split][65536]; zeroed by the caller of the atomic kernel
+  unsigned int* hist_counts;     // [n_frames][hist_split][65536]
+  int hist_is_clean;             // the first n_frames * 65536 counters are known to be zero (the atomic kernel's launcher then skips its memset)
+  int hist_zero_after;           // set by the launcher: the row transforms hand the counters they read back zeroed (atomic kernel)
   int hist_split;                // partial histograms per frame the LDS-histogram kernel writes (ccc_hist_split of the batch the buffer was sized for)
   const float* accum_tab;        // [97201]
   float* work;                   // [n_frames][65536] complex
@@ -251,7 +253,12 @@ void launch_vig_image(const DevTables* tabs, uint32_t* image, hipStream_t stream
 void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream);
 // Returns false when the histogram launch failed: nothing after it was enqueued and the caller must not run the
 // state-advancing finalisation on stale data.
-bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t stream);
+// hist_left_clean (optional): set to 1 when the histogram counters of this batch are zero again once the launches have run
+// (the global-atomic kernel's path: the row transforms zero what they read), else 0.
+bool launch_ccc_estimate(const CccParams& p, const Tunables& tn, hipStream_t stream, int* hist_left_clean = nullptr);
+// Small batches (single frames above all: every dependent launch costs ~5 us of an estimator that takes ~45): the per-frame
+// argmax over the 256 row maxima is done by the finalisation kernel itself instead of a launch of its own.
+inline bool ccc_argmax_in_finalize(int n_frames) { return n_frames <= 8; }
 // Partial histograms per frame the LDS-histogram kernel may write for a batch of n frames (one 1024-thread workgroup each:
 // fewer than 128 frames would leave most CUs idle with one workgroup per frame); the histogram buffer holds n * this * 65536 counters.
 inline int ccc_hist_split(int n_frames) { return n_frames >= 192 ? 1 : (n_frames >= 96 ? 2 : 4); }
@@ -260,7 +267,8 @@ size_t launch_hbm_probe(int kind, const void* src, void* dst, size_t bytes, hipS
 // Turns raw statistics into FrameWb (grey-world / pca) or runs the ccc temporal filter + gains.
 void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
                         const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream,
-                        const unsigned* simple_hist = nullptr, float simple_p = 0.f, int simple_total = 0);
+                        const unsigned* simple_hist = nullptr, float simple_p = 0.f, int simple_total = 0,
+                        const float* ccc_row_best = nullptr, int* ccc_argmax_out = nullptr);
 // Returns false (and launches nothing) when a pitch or frame size exceeds the kernels' 32-bit addressing.
 bool launch_remap(const RemapParams& p, hipStream_t stream);
 // Which code path launch_chain would pick (for tests / DESIGN.md): 1 fast, 0 generic.

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void stats_generic_kernel(StatsParams p) {
 // ------------------------------------------------------------------------------------------------
 __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* st,
                                    const DevTables* tabs, FrameWb* out, int n_frames, const unsigned* simple_hist,
-                                   float simple_p, int simple_total) {
+                                   float simple_p, int simple_total, const float* ccc_row_best, int* ccc_argmax_out) {
   if (mode == WB_FLOAT) {
     // ccc (one workgroup): the temporal filter is sequential over the frames of the stream -- one lane walks it over
     // argmax values staged in LDS (a handful of float operations per frame) -- while loading the argmax pairs and turning
@@ -378,9 +378,44 @@ __global__ void wb_finalize_kernel(int mode, const FrameStats* stats, const int*
     for (int f0 = 0; f0 < n_frames; f0 += kChunk) {
       const int n = min(kChunk, n_frames - f0);
       __syncthreads();
-      for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        s_raw[i][0] = ccc_argmax[2 * (f0 + i)];
-        s_raw[i][1] = ccc_argmax[2 * (f0 + i) + 1];
+      if (ccc_row_best) {
+        // small batches (ccc_argmax_in_finalize): cv::minMaxLoc over the response -- first maximum in row-major order -- from
+        // the 256 row maxima of each frame, here instead of in a launch of its own (256 threads: one row each)
+        __shared__ float bv[256];
+        __shared__ int br[256];
+        const int t = threadIdx.x;
+        for (int i = 0; i < n; i++) {
+          const float* rb = ccc_row_best + (size_t)(f0 + i) * 256 * 2;
+          bv[t] = rb[2 * t];
+          br[t] = t;
+          __syncthreads();
+          for (int off = 128; off > 0; off >>= 1) {
+            if (t < off) {
+              const float ov = bv[t + off];
+              const int orow = br[t + off];
+              if (ov > bv[t] || (ov == bv[t] && orow < br[t])) {
+                bv[t] = ov;
+                br[t] = orow;
+              }
+            }
+            __syncthreads();
+          }
+          if (t == 0) {
+            const int row = br[0];
+            s_raw[i][0] = (int)rb[2 * row + 1];
+            s_raw[i][1] = row;
+            if (ccc_argmax_out) {
+              ccc_argmax_out[2 * (f0 + i)] = s_raw[i][0];
+              ccc_argmax_out[2 * (f0 + i) + 1] = row;
+            }
+          }
+          __syncthreads();
+        }
+      } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+          s_raw[i][0] = ccc_argmax[2 * (f0 + i)];
+          s_raw[i][1] = ccc_argmax[2 * (f0 + i) + 1];
+        }
       }
       __syncthreads();
       // A = Q = I, H = h I, R = r I: the two components of (u, v) never mix, so lane a walks component a (half the
@@ -580,14 +615,14 @@ void launch_stats(const StatsParams& p, const Tunables& tn, hipStream_t stream) 
 
 void launch_wb_finalize(int mode, const FrameStats* stats, const int* ccc_argmax, CccState* ccc_state,
                         const DevTables* tabs, FrameWb* out, int n_frames, hipStream_t stream, const unsigned* simple_hist,
-                        float simple_p, int simple_total) {
+                        float simple_p, int simple_total, const float* ccc_row_best, int* ccc_argmax_out) {
   if (n_frames <= 0) return;
   if (mode == WB_FLOAT) {
     hipLaunchKernelGGL(wb_finalize_kernel, dim3(1), dim3(256), 0, stream, mode, stats, ccc_argmax, ccc_state, tabs, out, n_frames,
-                       simple_hist, simple_p, simple_total);
+                       simple_hist, simple_p, simple_total, ccc_row_best, ccc_argmax_out);
   } else {
     hipLaunchKernelGGL(wb_finalize_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, mode, stats, ccc_argmax,
-                       ccc_state, tabs, out, n_frames, simple_hist, simple_p, simple_total);
+                       ccc_state, tabs, out, n_frames, simple_hist, simple_p, simple_total, nullptr, nullptr);
   }
 }
 

@@ -488,6 +488,59 @@ def test_ccc_lds_histogram_path(gpu_pipe, oracle, monkeypatch, size, pattern, fl
         assert_images_equal(outs["lds"][i], ref, "ccc lds histogram frame %d" % i, TOL_DECLARED)
 
 
+def test_ccc_histogram_is_handed_back_zeroed_across_path_switches(gpu_pipe, oracle):
+    """Small batches accumulate the log-chroma histogram with global atomics into counters the row transforms hand back
+    zeroed (one memset for a stream of single frames instead of one per frame), the per-frame argmax is folded into the
+    finalisation kernel, and up to four frames run their 256-point transforms on 64 one-wave workgroups per frame.  Everything
+    that writes those counters in between must be noticed: a batch on the LDS-histogram path (leaves real counts), SimpleWB
+    (its own histograms live in the same buffer), a larger batch (the buffer is reallocated), a change of image size.  Every
+    frame equals the oracle's (calculateHistogramFeature / computeResponse, convolutional_color_constancy.cpp:210-298)."""
+    import torch
+    filt, bias = synth.ccc_model()
+    gpu_pipe.set_ccc_model(filt, bias)
+    gpu_pipe.set_ccc_kalman_model(1.0, 10.0)
+    occ = oracle.CCC(filt, bias)
+    occ.set_kalman_model(1.0, 10.0)
+    c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=False)
+    c_simple = cfg(wb=True, wb_method="simple", wb_percentile=10.0)
+    seed = [8800]
+
+    def frames_of(n, w, h):
+        seed[0] += n
+        return np.stack([synth.gen_frame(w, h, "bayer_grbg8", seed=seed[0] + i, kind="scene", tint=(0.55 + 0.04 * ((seed[0] + i) % 9), 1.0, 0.5)) for i in range(n)])
+
+    def check(n, w=384, h=240, resident=True):
+        fr = frames_of(n, w, h)
+        if resident:
+            out = gpu_pipe.apply_device(torch.from_numpy(fr).cuda(), "bayer_grbg8").cpu().numpy()
+        else:
+            out = np.stack([gpu_pipe.process(f, "bayer_grbg8") for f in fr])
+        for i in range(n):
+            ref, _ = oracle_run(oracle, c, fr[i], "bayer_grbg8", ccc=occ)
+            assert_images_equal(out[i], ref, "ccc, batch of %d (%dx%d), frame %d" % (n, w, h, i), TOL_DECLARED)
+
+    configure(gpu_pipe, c)
+    check(1)                    # first use: memset
+    check(1)                    # counters handed back zeroed: no memset
+    check(3, resident=False)    # three host frames, one after the other
+    check(4)                    # transforms on one-wave workgroups, argmax in the finalisation (<= 8 frames)
+    check(7)                    # 16-column transforms, argmax still folded
+    check(9)                    # own argmax launch
+    check(16)                   # LDS-histogram path: the counters stay dirty (and the buffer grew)
+    check(1)                    # must clear again
+    check(2)
+    configure(gpu_pipe, c_simple)   # SimpleWB writes its 3 x 256 bins into the same buffer
+    fr = frames_of(2, 384, 240)
+    out = gpu_pipe.apply_device(torch.from_numpy(fr).cuda(), "bayer_grbg8").cpu().numpy()
+    for i in range(2):
+        ref, _ = oracle_run(oracle, c_simple, fr[i], "bayer_grbg8")
+        assert_images_equal(out[i], ref, "simple wb between ccc frames, frame %d" % i, TOL_DECLARED)
+    configure(gpu_pipe, c)
+    check(1)
+    check(1, w=720, h=540)      # another geometry (exact 2 x area resize)
+    check(2, w=250, h=190, resident=False)
+
+
 def test_config5_full_size_3840x2160_debayer_undistort(gpu_pipe, oracle):
     """BASELINE configs[4] at its own size: 3840x2160 rggb8, debayer + fisheye undistortion."""
     w, h = 3840, 2160
