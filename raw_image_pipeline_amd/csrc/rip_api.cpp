@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -120,6 +122,51 @@ struct Plan {
 
 // One frame in flight on the asynchronous host path (rip_submit / rip_collect): its own device input / output / tap
 // buffers, a pinned result buffer, and the three events that chain upload -> kernels -> download.
+// Device-wide limit on the host frames in flight (rip_submit).  Measured on MI355X / ROCm 7.2 (tools/probes/ring_depth_probe.py,
+// rig_ring_probe.py, EXPERIMENTS.md): with three frames' uploads, kernels and downloads enqueued on their streams a 15 MB
+// download takes 0.295 ms; from the fourth frame on -- one handle with a deeper ring, or several handles on one device -- some
+// downloads take 1.19 ms or several ms (the runtime's handling of cross-stream dependencies of SDMA copies under direct
+// dispatch: the effect is gone with AMD_DIRECT_DISPATCH=0), and the whole pipeline runs at half its rate.  So rip_submit
+// waits for the oldest frame in flight on the device to finish before it enqueues a fourth one -- work that has to finish
+// before the new frame's download can start anyway.  RIP_RING_INFLIGHT changes the limit (0 = none).
+struct InflightGate {
+  std::mutex mu;
+  std::deque<hipEvent_t> q[64];  // per device: ev_done of the frames enqueued and not yet known to be complete, oldest first
+  int cap() {
+    static const int c = [] {
+      const char* e = std::getenv("RIP_RING_INFLIGHT");
+      return e ? std::max(0, std::atoi(e)) : 3;
+    }();
+    return c;
+  }
+  void admit(int device) {
+    const int c = cap();
+    if (c <= 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& d = q[device & 63];
+    while ((int)d.size() >= c) {
+      hipEvent_t e = d.front();
+      d.pop_front();
+      (void)hipEventSynchronize(e);
+    }
+  }
+  void enqueued(int device, hipEvent_t e) {
+    if (cap() <= 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    q[device & 63].push_back(e);
+  }
+  void forget(hipEvent_t e) {  // the frame is complete, or its event is about to be destroyed / recorded again
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& d : q)
+      for (auto it = d.begin(); it != d.end();) it = (*it == e) ? d.erase(it) : it + 1;
+  }
+};
+InflightGate& inflight_gate() {
+  static InflightGate g;
+  return g;
+}
+
 struct RingSlot {
   DevBuf d_in, d_out, d_tap_deb, d_tap_col;
   void* h_out = nullptr;  // hipHostMalloc
@@ -129,6 +176,7 @@ struct RingSlot {
   void* h_tap[2] = {nullptr, nullptr};  // hipHostMalloc: the debayered / colour taps of the frame, downloaded with the result
   size_t h_tap_cap[2] = {0, 0};
   hipEvent_t ev_up = nullptr, ev_kernels = nullptr, ev_done = nullptr;
+  hipEvent_t ev_start = nullptr, ev_dl_start = nullptr;  // RIP_DEBUG_RING only: before the upload / the download (the other three then carry timestamps too)
   uint64_t ticket = 0;
   bool busy = false;  // submitted, not collected yet
   bool held = false;  // collected: the pinned result and the taps stay put until the next collect (or until a submit needs the slot)
@@ -164,7 +212,8 @@ struct RingSlot {
       h_tap[i] = nullptr;
       h_tap_cap[i] = 0;
     }
-    for (hipEvent_t* e : {&ev_up, &ev_kernels, &ev_done}) {
+    inflight_gate().forget(ev_done);
+    for (hipEvent_t* e : {&ev_up, &ev_kernels, &ev_done, &ev_start, &ev_dl_start}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }
@@ -1370,7 +1419,10 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     if (!p->dl_stream) HIP_CHECK(hipStreamCreateWithFlags(&p->dl_stream, hipStreamNonBlocking));
     while ((int)p->ring.size() < p->ring_depth) {
       std::unique_ptr<RingSlot> sl(new RingSlot());
-      for (hipEvent_t* e : {&sl->ev_up, &sl->ev_kernels, &sl->ev_done}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      static const bool debug_ring = std::getenv("RIP_DEBUG_RING") != nullptr;  // development aid: per-frame upload / kernel / download times on stderr
+      for (hipEvent_t* e : {&sl->ev_up, &sl->ev_kernels, &sl->ev_done}) HIP_CHECK(hipEventCreateWithFlags(e, debug_ring ? hipEventDefault : hipEventDisableTiming));
+      if (debug_ring) HIP_CHECK(hipEventCreateWithFlags(&sl->ev_start, hipEventDefault));
+      if (debug_ring) HIP_CHECK(hipEventCreateWithFlags(&sl->ev_dl_start, hipEventDefault));
       p->ring.push_back(std::move(sl));
     }
     // a free slot; failing that the slot of the frame collected last (its view and taps end here); failing that: full
@@ -1416,6 +1468,9 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     // caller's buffer is free again when this call returns whatever the runtime does with an asynchronous 2-D copy from
     // pageable memory (above its staging threshold it pins the pages in place and copies after the call has returned).
     const size_t row_bytes = (size_t)cols * channels * eb;
+    inflight_gate().forget(sl.ev_done);  // the slot's previous frame (collected, or it would not have been picked)
+    inflight_gate().admit(p->device);
+    if (sl.ev_start) HIP_CHECK(hipEventRecord(sl.ev_start, p->ul_stream));
     if (host_pointer_is_pinned(image)) {
       HIP_CHECK(hipMemcpy2DAsync(sl.d_in.ptr, in_pitch, image, step, row_bytes, (size_t)rows, hipMemcpyHostToDevice, p->ul_stream));
     } else {
@@ -1434,6 +1489,7 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
               sl.has_deb ? sl.d_tap_deb.as<uint8_t>() : nullptr, sl.has_col ? sl.d_tap_col.as<uint8_t>() : nullptr);
     HIP_CHECK(hipEventRecord(sl.ev_kernels, p->stream));
     HIP_CHECK(hipStreamWaitEvent(p->dl_stream, sl.ev_kernels, 0));
+    if (sl.ev_dl_start) HIP_CHECK(hipEventRecord(sl.ev_dl_start, p->dl_stream));
     HIP_CHECK(hipMemcpyAsync(sl.h_out, sl.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, p->dl_stream));
     // the taps rip_set_tap_download names travel with the result: a per-frame caller that publishes them
     // (raw_image_pipeline_ros.cpp:245-287: up to three images per callback) gets them from pinned host memory instead of
@@ -1442,6 +1498,7 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     if (sl.dl_deb) HIP_CHECK(hipMemcpyAsync(sl.h_tap[0], sl.d_tap_deb.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
     if (sl.dl_col) HIP_CHECK(hipMemcpyAsync(sl.h_tap[1], sl.d_tap_col.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
     HIP_CHECK(hipEventRecord(sl.ev_done, p->dl_stream));
+    inflight_gate().enqueued(p->device, sl.ev_done);
     sl.pl = pl;
     sl.ticket = p->next_ticket++;
     sl.busy = true;
@@ -1462,6 +1519,20 @@ rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t ou
     if (out && out_capacity < out_bytes) throw CapacityError("output buffer too small: need " + std::to_string(out_bytes) + " bytes");
     DeviceGuard device_guard(p->device);
     HIP_CHECK(hipEventSynchronize(sl->ev_done));
+    inflight_gate().forget(sl->ev_done);
+    if (sl->ev_start) {
+      float up = 0, kern = 0, down = 0, all = 0, copy = 0;
+      (void)hipEventElapsedTime(&copy, sl->ev_dl_start, sl->ev_done);
+      (void)hipEventElapsedTime(&up, sl->ev_start, sl->ev_up);
+      (void)hipEventElapsedTime(&kern, sl->ev_up, sl->ev_kernels);
+      (void)hipEventElapsedTime(&down, sl->ev_kernels, sl->ev_done);
+      (void)hipEventElapsedTime(&all, sl->ev_start, sl->ev_done);
+      int idx = 0;
+      for (size_t i = 0; i < p->ring.size(); i++)
+        if (p->ring[i].get() == sl) idx = (int)i;
+      std::fprintf(stderr, "rip ring: ticket %llu slot %d upload %.3f ms, kernels (incl. waiting for the frame before) %.3f, download (incl. waiting) %.3f of which the copies %.3f, total %.3f\n",
+                   (unsigned long long)ticket, idx, up, kern, down, copy, all);
+    }
     if (out) std::memcpy(out, sl->h_out, out_bytes);
     if (out_view) *out_view = static_cast<const uint8_t*>(sl->h_out);
     for (auto& c : p->ring) c->held = false;  // the frame collected before this one lets go of its slot

@@ -726,7 +726,45 @@ def test_debug_stage_dumps_do_not_advance_the_ccc_filter_and_handle_mono(rip_lib
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("depth", [1, 3])
+def test_a_deeper_ring_is_not_slower(rip_lib):
+    """More than three host frames enqueued on one device -- a ring deeper than the default, or several handles -- made every
+    other 15 MB download take 1.2 ms or more instead of 0.3 (the runtime's handling of SDMA copies behind cross-stream waits),
+    and a ring of six ran at 0.76 ms per frame instead of 0.30.  rip_submit therefore lets at most three frames be in flight
+    per device (RIP_RING_INFLIGHT); with that a deeper ring costs nothing.  Generous margin: 0.76 against 0.30 is the effect."""
+    import time
+    from raw_image_pipeline_amd import RawImagePipeline
+    from raw_image_pipeline_amd.pipeline import host_alloc
+    w, h = 2448, 2048
+    frame = host_alloc((h, w))
+    frame[...] = synth.gen_frame(w, h, "bayer_rggb8", seed=1, kind="scene")
+
+    def ms_per_frame(depth, n=120):
+        pipe = RawImagePipeline(False, "", "", "", device=0)
+        synth.configure_full_chain(pipe, w, h, "grey_world")
+        pipe.set_ring_depth(depth)
+        best = 1e9
+        for _ in range(3):
+            tickets = []
+            for _ in range(2 * depth):
+                if len(tickets) == depth:
+                    pipe.collect(tickets.pop(0), copy=False)
+                tickets.append(pipe.submit(frame, "bayer_rggb8"))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                if len(tickets) == depth:
+                    pipe.collect(tickets.pop(0), copy=False)
+                tickets.append(pipe.submit(frame, "bayer_rggb8"))
+            while tickets:
+                pipe.collect(tickets.pop(0), copy=False)
+            best = min(best, (time.perf_counter() - t0) / n * 1e3)
+        return best
+
+    t3, t6 = ms_per_frame(3), ms_per_frame(6)
+    assert t6 <= 1.5 * t3, "ring of 6: %.3f ms per frame, ring of 3: %.3f" % (t6, t3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [1, 3, 6])
 def test_submit_collect_stream_of_32_frames_ccc_temporal(rip_lib, oracle, depth):
     """The asynchronous host path (rip_submit / rip_collect, what a streaming caller like raw_image_pipeline_ros.cpp:219-288
     would use): 32 frames of a ccc + temporal-consistency stream with up to `depth` frames in flight.  Every collected frame
