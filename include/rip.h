@@ -129,6 +129,11 @@ rip_status rip_set_ring_depth(rip_pipeline* p, int depth);
  * and run at the full PCIe rate.  NULL when the allocation fails. */
 void* rip_host_alloc(size_t bytes);
 void rip_host_free(void* ptr);
+/* memcpy for whole frames: the deep copies the reference's API hands out (process(), every image getter: cpp:182-236) of a
+ * 15 MB result are slower on one host thread than the frame's kernels and PCIe transfers together; copies of 4 MB and more
+ * are split over a few library threads (RIP_COPY_THREADS, default 3 beside the caller; 0 = plain memcpy).  rip_collect and
+ * rip_get_image copy this way themselves; this entry is for callers that copy out of a view. */
+void rip_copy_host(void* dst, const void* src, size_t bytes);
 
 /* Image getters (hpp:134-137, cpp:222-236): copy of the tap of the most recent rip_apply
  * frame.  RIP_IMAGE_RECT_MASK is always empty (rows = cols = 0): the reference never writes

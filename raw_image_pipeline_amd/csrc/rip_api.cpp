@@ -10,9 +10,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -122,6 +124,71 @@ struct Plan {
 
 // One frame in flight on the asynchronous host path (rip_submit / rip_collect): its own device input / output / tap
 // buffers, a pinned result buffer, and the three events that chain upload -> kernels -> download.
+// Host-side copies of whole frames (the deep copies the reference's API promises: process() and every image getter return a
+// clone, raw_image_pipeline.cpp:182-236): a 15 MB memcpy out of the pinned result buffer into freshly allocated pages takes
+// 0.4-0.7 ms on one thread -- more than the frame's kernels and its PCIe transfer together -- so copies of 4 MB and more are
+// split over a few worker threads (page faults of a fresh destination included).  The pool is created on first use, leaked on
+// purpose (its threads may outlive static destruction) and serves one copy at a time; a second caller copies on its own thread.
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static CopyPool* pool = new CopyPool();
+    return *pool;
+  }
+  void copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < (size_t(4) << 20) || workers_ == 0 || !busy_.try_lock()) {
+      std::memcpy(dst, src, bytes);
+      return;
+    }
+    std::lock_guard<std::mutex> whole(busy_, std::adopt_lock);
+    std::unique_lock<std::mutex> lk(mu_);
+    dst_ = static_cast<uint8_t*>(dst);
+    src_ = static_cast<const uint8_t*>(src);
+    bytes_ = bytes;
+    parts_ = workers_ + 1;
+    chunk_ = ((bytes + (size_t)parts_ - 1) / (size_t)parts_ + 4095) & ~size_t(4095);
+    next_ = done_ = 0;
+    wake_.notify_all();
+    work(lk);
+    finished_.wait(lk, [&] { return done_ == parts_; });
+    parts_ = 0;
+  }
+
+ private:
+  CopyPool() {
+    const char* e = std::getenv("RIP_COPY_THREADS");  // worker threads beside the caller; 0 = plain memcpy
+    const int hw = (int)std::thread::hardware_concurrency();
+    workers_ = e ? std::max(0, std::min(16, std::atoi(e))) : std::max(0, std::min(3, hw - 1));
+    for (int i = 0; i < workers_; i++)
+      std::thread([this] {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+          wake_.wait(lk, [&] { return next_ < parts_; });
+          work(lk);
+        }
+      }).detach();
+  }
+  // claims parts of the current copy until none is left; called and left with the lock held
+  void work(std::unique_lock<std::mutex>& lk) {
+    while (next_ < parts_) {
+      const size_t off = (size_t)next_++ * chunk_;
+      uint8_t* d = dst_;
+      const uint8_t* s = src_;
+      const size_t n = off < bytes_ ? std::min(chunk_, bytes_ - off) : 0;
+      lk.unlock();
+      if (n) std::memcpy(d + off, s + off, n);
+      lk.lock();
+      if (++done_ == parts_) finished_.notify_all();
+    }
+  }
+  std::mutex busy_, mu_;
+  std::condition_variable wake_, finished_;
+  uint8_t* dst_ = nullptr;
+  const uint8_t* src_ = nullptr;
+  size_t bytes_ = 0, chunk_ = 0;
+  int parts_ = 0, next_ = 0, done_ = 0, workers_ = 0;
+};
+
 // Device-wide limit on the host frames in flight (rip_submit).  Measured on MI355X / ROCm 7.2 (tools/probes/ring_depth_probe.py,
 // rig_ring_probe.py, EXPERIMENTS.md): with three frames' uploads, kernels and downloads enqueued on their streams a 15 MB
 // download takes 0.295 ms; from the fourth frame on -- one handle with a deeper ring, or several handles on one device -- some
@@ -1477,7 +1544,7 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
       sl.reserve_host_in(in_bytes);
       uint8_t* stage = static_cast<uint8_t*>(sl.h_in);
       if (step == in_pitch) {
-        std::memcpy(stage, image, in_pitch * (size_t)(rows - 1) + row_bytes);
+        CopyPool::get().copy(stage, image, in_pitch * (size_t)(rows - 1) + row_bytes);
       } else {
         for (int r = 0; r < rows; r++) std::memcpy(stage + (size_t)r * in_pitch, image + (size_t)r * step, row_bytes);
       }
@@ -1533,7 +1600,7 @@ rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t ou
       std::fprintf(stderr, "rip ring: ticket %llu slot %d upload %.3f ms, kernels (incl. waiting for the frame before) %.3f, download (incl. waiting) %.3f of which the copies %.3f, total %.3f\n",
                    (unsigned long long)ticket, idx, up, kern, down, copy, all);
     }
-    if (out) std::memcpy(out, sl->h_out, out_bytes);
+    if (out) CopyPool::get().copy(out, sl->h_out, out_bytes);
     if (out_view) *out_view = static_cast<const uint8_t*>(sl->h_out);
     for (auto& c : p->ring) c->held = false;  // the frame collected before this one lets go of its slot
     sl->busy = false;
@@ -1588,6 +1655,9 @@ void* rip_host_alloc(size_t bytes) {
 void rip_host_free(void* ptr) {
   if (ptr) (void)hipHostFree(ptr);
 }
+void rip_copy_host(void* dst, const void* src, size_t bytes) {
+  if (dst && src && bytes) CopyPool::get().copy(dst, src, bytes);
+}
 
 rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_capacity, int* rows, int* cols, int* channels) {
   return guarded(p, [&] {
@@ -1608,7 +1678,7 @@ rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_ca
     if (out_capacity < bytes) throw CapacityError("image buffer too small");
     need_device(p);
     if (p->last_host[which]) {  // a frame that came through rip_collect: the image is in pinned host memory already
-      std::memcpy(out, p->last_host[which], bytes);
+      CopyPool::get().copy(out, p->last_host[which], bytes);
       return;
     }
     DeviceGuard device_guard(p->device);

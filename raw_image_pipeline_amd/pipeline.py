@@ -56,6 +56,8 @@ def load_library(path=None):
     lib.rip_version.restype = C.c_char_p
     lib.rip_destroy.restype = None
     lib.rip_destroy.argtypes = [C.c_void_p]
+    lib.rip_copy_host.restype = None
+    lib.rip_copy_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
     return lib
 
@@ -210,11 +212,13 @@ class RawImagePipeline:
         self.last_encoding = enc.value.decode()
         wide = self.last_encoding.endswith("16")
         n = r.value * c.value * k.value
+        shape = (r.value, c.value) if k.value == 1 else (r.value, c.value, k.value)
+        if copy:  # the library's copy (split over a few threads for whole frames), not numpy's
+            out = np.empty(shape, np.uint16 if wide else np.uint8)
+            self._lib.rip_copy_host(out.ctypes.data_as(C.c_void_p), view, C.c_size_t(out.nbytes))
+            return out
         buf = (C.c_uint16 if wide else C.c_uint8) * n
-        arr = np.frombuffer(buf.from_address(view.value), np.uint16 if wide else np.uint8)
-        arr = arr.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
-        if copy:
-            return arr.copy()
+        arr = np.frombuffer(buf.from_address(view.value), np.uint16 if wide else np.uint8).reshape(shape)
         arr.flags.writeable = False
         return arr
 

@@ -58,3 +58,39 @@ def test_version_and_error_strings(rip_lib):
     assert b"9 values" in rip_lib.rip_last_error(h)
     assert rip_lib.rip_load_ccc_model(h, b"/nonexistent/model.bin") == 3
     rip_lib.rip_destroy(h)
+
+
+def test_copy_host_copies_every_size_and_survives_concurrent_callers(rip_lib):
+    """rip_copy_host (the split memcpy behind rip_collect's / rip_get_image's deep copies): sizes around the 4 MB threshold
+    and odd ones byte for byte, nothing written past the end, four threads copying at once (one at a time gets the pool,
+    the others copy on their own thread)."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    lib = rip_lib
+    lib.rip_copy_host.restype = None
+    lib.rip_copy_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 4095, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, 2448 * 2048 * 3, (16 << 20) + 3):
+        src = rng.integers(0, 256, n, dtype=np.uint8)
+        dst = np.zeros(n + 16, np.uint8)
+        lib.rip_copy_host(dst.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+        assert np.array_equal(dst[:n], src) and not dst[n:].any(), n
+    errors = []
+
+    def worker(seed):
+        r = np.random.default_rng(seed)
+        for _ in range(8):
+            n = int(r.integers(1 << 20, 12 << 20))
+            src = r.integers(0, 256, n, dtype=np.uint8)
+            dst = np.empty(n, np.uint8)
+            lib.rip_copy_host(dst.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+            if not np.array_equal(dst, src):
+                errors.append((seed, n))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
