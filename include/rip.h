@@ -112,7 +112,10 @@ rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, s
  * rip_submit fails with RIP_ERR_CAPACITY and changes nothing.  A pageable `image` is read before rip_submit returns
  * (the library copies it into a pinned staging buffer of the frame's slot -- it does not rely on what the HIP runtime does
  * with an asynchronous copy from pageable memory); pinned memory (rip_host_alloc(), hipHostMalloc, hipHostRegister) is read
- * asynchronously, with no staging copy, and must stay untouched until the frame's rip_collect().  Debug dumps (rip_set_debug) are written by rip_apply only. */
+ * asynchronously, with no staging copy, and must stay untouched until the frame's rip_collect().  Debug dumps (rip_set_debug) are written by rip_apply only.
+ * Whatever the depth, at most three host frames are in flight per DEVICE (all handles together; RIP_RING_INFLIGHT, 0 = no
+ * limit): rip_submit waits for the oldest one to finish first -- beyond three the runtime's downloads slow down fourfold
+ * (measured: tools/probes/ring_depth_probe.py), so a deeper ring only adds slots whose results can be held longer. */
 rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step,
                       const char* encoding, uint64_t* ticket);
 /* Waits for the frame of `ticket` (tickets of one handle may be collected in any order) and hands over the result:
