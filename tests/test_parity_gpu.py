@@ -764,6 +764,50 @@ def test_a_deeper_ring_is_not_slower(rip_lib):
 
 
 @pytest.mark.gpu
+def test_three_threads_stream_through_their_own_handles_under_the_in_flight_limit(rip_lib):
+    """The device-wide in-flight limit is shared by every handle of the process: three threads, each streaming 40 frames
+    through its own handle with a ring of four (so the limit is hit constantly and a thread regularly waits for another
+    thread's frame), deep copies through the shared copy pool.  No deadlock, and every result equals the synchronous
+    process() of the same frame on a fourth handle."""
+    import threading
+    from raw_image_pipeline_amd import RawImagePipeline
+    w, h, n = 1008, 502, 40
+    frames = [synth.gen_frame(w, h, "bayer_gbrg8", seed=9100 + i, kind="scene") for i in range(6)]
+    ref_pipe = RawImagePipeline(False, "", "", "", device=0)
+    synth.configure_full_chain(ref_pipe, w, h, "grey_world")
+    want = [ref_pipe.process(f, "bayer_gbrg8") for f in frames]
+    errors = []
+
+    def stream(k):
+        try:
+            pipe = RawImagePipeline(False, "", "", "", device=0)
+            synth.configure_full_chain(pipe, w, h, "grey_world")
+            pipe.set_ring_depth(4)
+            tickets = []
+            for i in range(n):
+                if len(tickets) == 4:
+                    j, t = tickets.pop(0)
+                    got = pipe.collect(t, copy=(i % 2 == 0))
+                    if not np.array_equal(got, want[j]):
+                        errors.append("thread %d frame %d differs" % (k, j))
+                j = (i + k) % len(frames)
+                tickets.append((j, pipe.submit(frames[j], "bayer_gbrg8")))
+            for j, t in tickets:
+                if not np.array_equal(pipe.collect(t), want[j]):
+                    errors.append("thread %d tail frame %d differs" % (k, j))
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=stream, args=(k,), daemon=True) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a streaming thread did not finish: deadlock under the in-flight limit"
+    assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("depth", [1, 3, 6])
 def test_submit_collect_stream_of_32_frames_ccc_temporal(rip_lib, oracle, depth):
     """The asynchronous host path (rip_submit / rip_collect, what a streaming caller like raw_image_pipeline_ros.cpp:219-288
