@@ -68,7 +68,8 @@ void rip_destroy(rip_pipeline* p);
  * this thread).  Valid until the next call on the handle. */
 const char* rip_last_error(const rip_pipeline* p);
 /* HIP stream (hipStream_t) all device work of this handle is enqueued on; default: the
- * null stream.  The caller keeps ownership. */
+ * null stream.  The caller keeps ownership.  A switch orders the new stream behind the work this handle left on the old
+ * one (its scratch state crosses frame calls in stream order). */
 rip_status rip_set_stream(rip_pipeline* p, void* hip_stream);
 
 /* ---- frame API ----------------------------------------------------------------------- */

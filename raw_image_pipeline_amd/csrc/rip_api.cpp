@@ -334,6 +334,7 @@ struct rip_pipeline {
   int plan_n_border = 0;
   bool use_tiled_remap = true;
   int last_batch_frames = 0;
+  bool work_enqueued = false;  // some frame call has put work on `stream` (rip_set_stream orders a new stream behind it)
   // prefix of d_stats known to hold zeroed FrameStats records (the grey-world / pca statistics kernels clean up after themselves)
   const void* stats_clean_ptr = nullptr;
   size_t stats_clean_cap = 0, stats_clean_bytes = 0;  // (pointer, capacity) identify the allocation: DevBuf only ever grows
@@ -345,6 +346,7 @@ struct rip_pipeline {
   // statistics and the fused chain of group g + 1 run on the caller's stream
   hipStream_t aux_stream = nullptr;
   std::vector<hipEvent_t> ovl_events;
+  hipEvent_t switch_event = nullptr;  // rip_set_stream: orders the new stream behind the work left on the old one
   // asynchronous host path: frames in flight (rip_submit / rip_collect), upload and download streams
   std::vector<std::unique_ptr<RingSlot>> ring;
   int ring_depth = 3;
@@ -367,6 +369,7 @@ struct rip_pipeline {
     (void)hipSetDevice(device);
     for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ovl_events) (void)hipEventDestroy(e);
+    if (switch_event) (void)hipEventDestroy(switch_event);
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
     if (ul_stream) (void)hipStreamSynchronize(ul_stream);
     if (dl_stream) (void)hipStreamSynchronize(dl_stream);
@@ -778,6 +781,7 @@ Plan make_plan(const rip_pipeline* p, int rows, int cols, int channels, const st
 void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_step, size_t in_frame_stride, int n, int rows,
                int cols, uint8_t* d_out, size_t out_step, size_t out_frame_stride, uint8_t* d_tap_deb, uint8_t* d_tap_col,
                bool reuse_wb = false) {
+  p->work_enqueued = true;  // from here on something may sit on p->stream
   DeviceGuard device_guard(p->device);
   if (pl.elem_bytes == 2) {  // 16-bit Bayer extension: one kernel, no taps
     rip::Debayer16Params d = {};
@@ -1344,7 +1348,18 @@ const char* rip_last_error(const rip_pipeline* p) { return p ? p->last_error.c_s
 rip_status rip_set_stream(rip_pipeline* p, void* s) {
   return guarded(p, [&] {
     need_device(p);
-    p->stream = static_cast<hipStream_t>(s);
+    hipStream_t next = static_cast<hipStream_t>(s);
+    if (next != p->stream && p->work_enqueued) {
+      // The handle's scratch state crosses frame calls in stream order (statistics records and ccc histogram counters handed
+      // back zeroed by the kernels of the call before, the ccc Kalman state, the gains the debug dumps reuse): work left on
+      // the old stream must come first on the new one too.  Best effort -- a stream the caller has destroyed already has
+      // nothing pending and the runtime refuses the record, which is ignored.
+      DeviceGuard device_guard(p->device);
+      if (!p->switch_event && hipEventCreateWithFlags(&p->switch_event, hipEventDisableTiming) != hipSuccess) p->switch_event = nullptr;
+      if (p->switch_event && hipEventRecord(p->switch_event, p->stream) == hipSuccess) (void)hipStreamWaitEvent(next, p->switch_event, 0);
+      (void)hipGetLastError();
+    }
+    p->stream = next;
   });
 }
 

@@ -71,3 +71,36 @@ def test_full_step_is_bit_identical_over_repetitions_and_ring_settings(rip_lib):
         assert torch.equal(out, first), "repetition %d (%s) differs from the first result" % (i, st or "defaults")
     single = pipe.process(base[1], "bayer_rggb8")
     assert np.array_equal(first[1].cpu().numpy(), single) and np.array_equal(first[46].cpu().numpy(), single)
+
+
+@pytest.mark.gpu
+def test_switching_streams_between_frame_calls_keeps_the_scratch_state_ordered(rip_lib):
+    """The handle's scratch state crosses frame calls in stream order (statistics records and ccc histogram counters handed
+    back zeroed by the previous call's kernels, the Kalman state).  rip_set_stream orders the new stream behind the work left
+    on the old one, so a caller may alternate streams from call to call without synchronising: 40 resident single frames,
+    ccc with temporal consistency and grey-world, alternating between three streams, equal the same sequence on one stream."""
+    import torch
+    from raw_image_pipeline_amd import RawImagePipeline, synth
+    w, h, n = 1440, 1080, 40
+    frames = torch.from_numpy(np.stack([synth.gen_frame(w, h, "bayer_gbrg8", seed=9300 + i, kind="scene", tint=(0.55 + 0.01 * i, 1.0, 0.6)) for i in range(n)])).cuda()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    filt, bias = synth.ccc_model()
+    for method in ("ccc", "grey_world"):
+        outs = []
+        for alternate in (False, True):
+            pipe = RawImagePipeline(False, "", "", "", device=0)
+            synth.configure_full_chain(pipe, w, h, "grey_world")
+            if method == "ccc":
+                pipe.set_ccc_model(filt, bias)
+                pipe.set_ccc_kalman_model(1.0, 10.0)
+                pipe.set_white_balance_method("ccc")
+                pipe.set_white_balance_temporal_consistency(True)
+            out = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            for i in range(n):
+                st = streams[i % 3] if alternate else streams[0]
+                pipe.set_stream(st)
+                pipe.apply_device(frames[i:i + 1], "bayer_gbrg8", out=out[i:i + 1])
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]), "%s: alternating streams changed %d values" % (method, int((outs[0] != outs[1]).sum()))
