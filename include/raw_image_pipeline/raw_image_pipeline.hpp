@@ -142,7 +142,14 @@ class RawImagePipeline {
     check(rip_submit(h_, detail::bytes(image), image.rows, image.cols, image.channels(), detail::step_of(image), encoding.c_str(), &ticket));
     return ticket;
   }
-  Mat collect(uint64_t ticket, std::string& encoding) { return collectView(ticket, encoding).clone(); }
+  Mat collect(uint64_t ticket, std::string& encoding) {
+    // the clone the reference's process() / getters promise, through the library's split copy (rip_copy_host): a 15 MB
+    // Mat::clone() on one thread takes longer than the frame's kernels and PCIe transfers together
+    const Mat view = collectView(ticket, encoding);
+    Mat out = detail::make_u8(view.rows, view.cols, view.channels());
+    rip_copy_host(detail::bytes(out), detail::bytes(view), (size_t)view.rows * view.cols * view.channels());
+    return out;
+  }
   Mat collectView(uint64_t ticket, std::string& encoding) {
     int rows = 0, cols = 0, cn = 0;
     char enc[32] = {0};
