@@ -119,6 +119,16 @@ rip_status rip_apply_device(rip_pipeline* p, const void* d_in, size_t in_step, s
  * (measured: tools/probes/ring_depth_probe.py), so a deeper ring only adds slots whose results can be held longer. */
 rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step,
                       const char* encoding, uint64_t* ticket);
+/* rip_submit with the destinations given by the caller: `out` (and, for the taps the handle keeps -- rip_set_taps --
+ * `tap_debayered` / `tap_color`; NULL = not wanted here) are page-locked buffers (rip_host_alloc, hipHostMalloc,
+ * hipHostRegister) the downloads are written into directly.  A caller that needs every frame in memory of its own -- the
+ * deep copies the reference's process() and getters hand out (cpp:182-236) -- gets them without a pinned buffer of the handle
+ * in between and without a memcpy: rip_collect only waits (its *out_view is `out`; the taps' views are the buffers given
+ * here).  The buffers must stay valid and untouched until the ticket is collected.  Capacities in bytes; a buffer that is
+ * too small, not page-locked, or a tap the handle does not keep: an error and nothing is enqueued. */
+rip_status rip_submit_to(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step,
+                         const char* encoding, uint8_t* out, size_t out_capacity, uint8_t* tap_debayered, uint8_t* tap_color,
+                         size_t tap_capacity, uint64_t* ticket);
 /* Waits for the frame of `ticket` (tickets of one handle may be collected in any order) and hands over the result:
  * copied into `out` (tightly packed, `out_capacity` bytes) when out != NULL, and / or as a pointer to the handle's pinned
  * buffer in *out_view when out_view != NULL -- no copy.  The view, and the taps rip_get_image returns afterwards (those of

@@ -241,6 +241,9 @@ struct RingSlot {
   void* h_in = nullptr;   // hipHostMalloc: staging copy of a pageable caller frame (the caller's buffer is free again when rip_submit returns)
   size_t h_in_cap = 0;
   void* h_tap[2] = {nullptr, nullptr};  // hipHostMalloc: the debayered / colour taps of the frame, downloaded with the result
+  // where this frame's downloads go: the slot's own pinned buffers above, or the page-locked buffers the caller gave rip_submit_to
+  void* dst_out = nullptr;
+  void* dst_tap[2] = {nullptr, nullptr};
   size_t h_tap_cap[2] = {0, 0};
   hipEvent_t ev_up = nullptr, ev_kernels = nullptr, ev_done = nullptr;
   hipEvent_t ev_start = nullptr, ev_dl_start = nullptr;  // RIP_DEBUG_RING only: before the upload / the download (the other three then carry timestamps too)
@@ -1490,12 +1493,25 @@ bool host_pointer_is_pinned(const void* ptr) {
 }
 }  // namespace
 
-rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step, const char* encoding,
-                      uint64_t* ticket) {
+namespace {
+rip_status submit_impl(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step, const char* encoding,
+                       uint8_t* ext_out, size_t ext_out_capacity, uint8_t* ext_deb, uint8_t* ext_col, size_t ext_tap_capacity,
+                       uint64_t* ticket) {
   return guarded(p, [&] {
     need_device(p);
     if (!image || !encoding || !ticket) throw InvalidArgument("null buffer, encoding or ticket");
     Plan pl = make_plan(p, rows, cols, channels, encoding);
+    {  // destinations given by the caller (rip_submit_to): checked before anything is enqueued or any slot is touched
+      const size_t eb0 = (size_t)pl.elem_bytes;
+      const size_t out_need = (size_t)pl.out_rows * pl.out_cols * pl.channels * eb0, mid_need = (size_t)pl.mid_rows * pl.mid_cols * pl.channels;
+      if (ext_out && ext_out_capacity < out_need) throw CapacityError("rip_submit_to: result buffer too small: need " + std::to_string(out_need) + " bytes");
+      if ((ext_deb || ext_col) && ext_tap_capacity < mid_need) throw CapacityError("rip_submit_to: tap buffer too small: need " + std::to_string(mid_need) + " bytes");
+      if (ext_deb && !((p->tap_mask & RIP_TAP_DEBAYERED) && eb0 == 1)) throw InvalidArgument("rip_submit_to: the debayered tap is not kept (rip_set_taps)");
+      if (ext_col && !((p->tap_mask & RIP_TAP_COLOR) && eb0 == 1)) throw InvalidArgument("rip_submit_to: the colour tap is not kept (rip_set_taps)");
+      for (const void* ptr : {(const void*)ext_out, (const void*)ext_deb, (const void*)ext_col})
+        if (ptr && !host_pointer_is_pinned(ptr))
+          throw InvalidArgument("rip_submit_to: destination buffers must be page-locked (rip_host_alloc, hipHostMalloc, hipHostRegister)");
+    }
     DeviceGuard device_guard(p->device);
     if (!p->ul_stream) HIP_CHECK(hipStreamCreateWithFlags(&p->ul_stream, hipStreamNonBlocking));
     if (!p->dl_stream) HIP_CHECK(hipStreamCreateWithFlags(&p->dl_stream, hipStreamNonBlocking));
@@ -1534,15 +1550,18 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     const size_t mid_bytes = (size_t)pl.mid_rows * pl.mid_cols * pl.channels;
     sl.d_in.reserve(in_bytes);
     sl.d_out.reserve(out_bytes);
-    sl.reserve_host(out_bytes);
+    if (!ext_out) sl.reserve_host(out_bytes);
     sl.has_deb = (p->tap_mask & RIP_TAP_DEBAYERED) && eb == 1;
     sl.has_col = (p->tap_mask & RIP_TAP_COLOR) && eb == 1;
-    sl.dl_deb = sl.has_deb && (p->tap_download_mask & RIP_TAP_DEBAYERED);
-    sl.dl_col = sl.has_col && (p->tap_download_mask & RIP_TAP_COLOR);
+    sl.dl_deb = sl.has_deb && ((p->tap_download_mask & RIP_TAP_DEBAYERED) || ext_deb);
+    sl.dl_col = sl.has_col && ((p->tap_download_mask & RIP_TAP_COLOR) || ext_col);
     if (sl.has_deb) sl.d_tap_deb.reserve(mid_bytes);
     if (sl.has_col) sl.d_tap_col.reserve(mid_bytes);
-    if (sl.dl_deb) RingSlot::reserve_pinned(sl.h_tap[0], sl.h_tap_cap[0], mid_bytes);
-    if (sl.dl_col) RingSlot::reserve_pinned(sl.h_tap[1], sl.h_tap_cap[1], mid_bytes);
+    if (sl.dl_deb && !ext_deb) RingSlot::reserve_pinned(sl.h_tap[0], sl.h_tap_cap[0], mid_bytes);
+    if (sl.dl_col && !ext_col) RingSlot::reserve_pinned(sl.h_tap[1], sl.h_tap_cap[1], mid_bytes);
+    sl.dst_out = ext_out ? (void*)ext_out : sl.h_out;
+    sl.dst_tap[0] = ext_deb ? (void*)ext_deb : sl.h_tap[0];
+    sl.dst_tap[1] = ext_col ? (void*)ext_col : sl.h_tap[1];
     // upload (its own stream: it overlaps the kernels of the frame before) -> kernels on the handle's stream, in submission
     // order -> download into the slot's pinned buffer (its own stream: it overlaps the kernels of the frame after)
     // A frame in pinned memory (rip_host_alloc, hipHostMalloc, hipHostRegister) is DMA'd from where it lies and must stay
@@ -1572,13 +1591,13 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     HIP_CHECK(hipEventRecord(sl.ev_kernels, p->stream));
     HIP_CHECK(hipStreamWaitEvent(p->dl_stream, sl.ev_kernels, 0));
     if (sl.ev_dl_start) HIP_CHECK(hipEventRecord(sl.ev_dl_start, p->dl_stream));
-    HIP_CHECK(hipMemcpyAsync(sl.h_out, sl.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, p->dl_stream));
+    HIP_CHECK(hipMemcpyAsync(sl.dst_out, sl.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, p->dl_stream));
     // the taps rip_set_tap_download names travel with the result: a per-frame caller that publishes them
     // (raw_image_pipeline_ros.cpp:245-287: up to three images per callback) gets them from pinned host memory instead of
     // one synchronous device read each (rip_get_image / rip_get_image_view after rip_collect).  Off by default: a caller that
     // only wants the final image must not pay 30 MB more PCIe traffic per 2448 x 2048 frame.
-    if (sl.dl_deb) HIP_CHECK(hipMemcpyAsync(sl.h_tap[0], sl.d_tap_deb.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
-    if (sl.dl_col) HIP_CHECK(hipMemcpyAsync(sl.h_tap[1], sl.d_tap_col.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
+    if (sl.dl_deb) HIP_CHECK(hipMemcpyAsync(sl.dst_tap[0], sl.d_tap_deb.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
+    if (sl.dl_col) HIP_CHECK(hipMemcpyAsync(sl.dst_tap[1], sl.d_tap_col.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
     HIP_CHECK(hipEventRecord(sl.ev_done, p->dl_stream));
     inflight_gate().enqueued(p->device, sl.ev_done);
     sl.pl = pl;
@@ -1586,6 +1605,16 @@ rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols,
     sl.busy = true;
     *ticket = sl.ticket;
   });
+}
+}  // namespace
+
+rip_status rip_submit(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step, const char* encoding,
+                      uint64_t* ticket) {
+  return submit_impl(p, image, rows, cols, channels, step, encoding, nullptr, 0, nullptr, nullptr, 0, ticket);
+}
+rip_status rip_submit_to(rip_pipeline* p, const uint8_t* image, int rows, int cols, int channels, size_t step, const char* encoding,
+                         uint8_t* out, size_t out_capacity, uint8_t* tap_debayered, uint8_t* tap_color, size_t tap_capacity, uint64_t* ticket) {
+  return submit_impl(p, image, rows, cols, channels, step, encoding, out, out_capacity, tap_debayered, tap_color, tap_capacity, ticket);
 }
 
 rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t out_capacity, const uint8_t** out_view, int* out_rows,
@@ -1615,8 +1644,8 @@ rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t ou
       std::fprintf(stderr, "rip ring: ticket %llu slot %d upload %.3f ms, kernels (incl. waiting for the frame before) %.3f, download (incl. waiting) %.3f of which the copies %.3f, total %.3f\n",
                    (unsigned long long)ticket, idx, up, kern, down, copy, all);
     }
-    if (out) CopyPool::get().copy(out, sl->h_out, out_bytes);
-    if (out_view) *out_view = static_cast<const uint8_t*>(sl->h_out);
+    if (out && out != sl->dst_out) CopyPool::get().copy(out, sl->dst_out, out_bytes);
+    if (out_view) *out_view = static_cast<const uint8_t*>(sl->dst_out);
     for (auto& c : p->ring) c->held = false;  // the frame collected before this one lets go of its slot
     sl->busy = false;
     sl->held = true;
@@ -1629,9 +1658,9 @@ rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t ou
       p->last_cols[which] = c;
       p->last_cn[which] = pl.channels;
     };
-    remember(RIP_IMAGE_DEBAYERED, &sl->d_tap_deb, sl->dl_deb ? sl->h_tap[0] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_deb);
-    remember(RIP_IMAGE_COLOR, &sl->d_tap_col, sl->dl_col ? sl->h_tap[1] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_col);
-    remember(RIP_IMAGE_PROCESSED, &sl->d_out, sl->h_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0 && eb1);
+    remember(RIP_IMAGE_DEBAYERED, &sl->d_tap_deb, sl->dl_deb ? sl->dst_tap[0] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_deb);
+    remember(RIP_IMAGE_COLOR, &sl->d_tap_col, sl->dl_col ? sl->dst_tap[1] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_col);
+    remember(RIP_IMAGE_PROCESSED, &sl->d_out, sl->dst_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0 && eb1);
     if (out_rows) *out_rows = pl.out_rows;
     if (out_cols) *out_cols = pl.out_cols;
     if (out_channels) *out_channels = pl.channels;

@@ -10,7 +10,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .pipeline import RawImagePipeline
+from .pipeline import OutputPool, RawImagePipeline
 
 # readParameter defaults of RawImagePipelineRos::loadParams (raw_image_pipeline_ros.cpp:36-182)
 NODE_DEFAULTS = OrderedDict([
@@ -67,6 +67,13 @@ class CameraStream:
         self._skipped_rect = 0  # skipped_images_for_slow_topic_rect_
         # raw_image_pipeline_ = std::make_unique<RawImagePipeline>(use_gpu)  (:52): the one-argument constructor
         self.pipe = pipeline if pipeline is not None else RawImagePipeline(bool(p["use_gpu"]), device=device)
+        if self.pipe.out_pool is None:
+            # the published images are deep copies (the reference clones every one, raw_image_pipeline.cpp:222-236); their
+            # arrays are recycled once the subscriber has dropped them -- a fresh 15 MB array costs more than filling it
+            self.pipe.out_pool = OutputPool()
+        # ... and on the pipelined path they are page-locked arrays the downloads are written into directly (rip_submit_to):
+        # no pinned buffer of the handle in between, no memcpy at collect()
+        self._pinned_pool = OutputPool(limit=12, pinned=True)
         self._configure()
         if ccc_model is not None:
             self.pipe.set_ccc_model(*ccc_model)
@@ -165,7 +172,20 @@ class CameraStream:
         if self.transport != "raw":
             encoding = "bgr8"
         self._sync_taps()
-        ticket = self.pipe.submit(img, encoding)
+        dst = {}
+        if self._pinned_pool is not None:
+            from .pipeline import TAP_COLOR, TAP_DEBAYERED
+            rows, cols = img.shape[:2]
+            cn = 1 if img.ndim == 2 else img.shape[2]
+            r, c, k, enc_out = self.pipe.query_output(rows, cols, cn, encoding)
+            if not enc_out.endswith("16"):
+                dst["out"] = self._pinned_pool.take((r, c) if k == 1 else (r, c, k))
+                tr, tc, tk = self.pipe.query_taps(rows, cols, cn, encoding)
+                if self._tap_mask & TAP_DEBAYERED:
+                    dst["tap_debayered"] = self._pinned_pool.take((tr, tc) if tk == 1 else (tr, tc, tk))
+                if self._tap_mask & TAP_COLOR:
+                    dst["tap_color"] = self._pinned_pool.take((tr, tc) if tk == 1 else (tr, tc, tk))
+        ticket = self.pipe.submit(img, encoding, **{key: arr for key, arr in dst.items() if arr is not None})
         self._inflight = getattr(self, "_inflight", [])
         self._inflight.append((ticket, stamp, frame_id))
         return True

@@ -8,6 +8,7 @@ missing GPU raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -86,6 +87,35 @@ def host_alloc(shape, dtype=np.uint8):
     return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
+class OutputPool:
+    """Destination arrays for the deep copies a pipeline hands out (``RawImagePipeline.out_pool``).  A fresh 15 MB numpy
+    array costs more than filling it -- the kernel zeroes every new page -- so the pool keeps the arrays it has handed out
+    and hands one out again once NOBODY else references it any more (CPython reference count: only the pool's own list
+    holds it; a view of an array keeps its base alive and therefore counts).  The caller still owns what it gets, for as long
+    as it keeps it: an array in use is never recycled.  At most ``limit`` arrays per shape are remembered."""
+
+    def __init__(self, limit=8, pinned=False):
+        self.limit = int(limit)
+        self.pinned = bool(pinned)  # page-locked arrays (host_alloc): ``submit(..., out=...)`` downloads straight into them
+        self._arrays = {}
+        self._refcount = getattr(sys, "getrefcount", None)
+
+    def take(self, shape, dtype=np.uint8):
+        key = (tuple(shape), np.dtype(dtype).str)
+        arrays = self._arrays.setdefault(key, [])
+        if self._refcount is not None:
+            for i in range(len(arrays)):
+                # references: the list, the call argument of getrefcount -- anything above is somebody else's
+                if self._refcount(arrays[i]) == 2:
+                    return arrays[i]
+        if self.pinned and not (self._refcount is not None and len(arrays) < self.limit):
+            return None  # page-locked memory is only worth its allocation when it is recycled: the caller copies instead
+        arr = host_alloc(shape, dtype) if self.pinned else np.empty(shape, dtype)
+        if self._refcount is not None and len(arrays) < self.limit:
+            arrays.append(arr)
+        return arr
+
+
 class RawImagePipeline:
     """Same surface as ``py_raw_image_pipeline.RawImagePipeline``.
 
@@ -114,6 +144,9 @@ class RawImagePipeline:
             self._raise(st, msg)
         self.device = int(device)
         self._torch_stream = None
+        self.out_pool = None  # an OutputPool: collect() / the image getters then recycle the arrays of their deep copies
+        self._given = {}       # ticket -> (out, tap_debayered, tap_color) arrays handed to submit()
+        self._given_last = (None, None, None)  # ... of the frame collected last (what the image getters return)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -155,6 +188,12 @@ class RawImagePipeline:
                    C.byref(cn), enc)
         return r.value, c.value, cn.value, enc.value.decode()
 
+    def query_taps(self, rows, cols, channels, encoding):
+        """Geometry of the debayered / colour taps (post-flip, pre-undistortion): rows, cols, channels."""
+        tr, tc, tcn = C.c_int(), C.c_int(), C.c_int()
+        self._call("rip_query_taps", int(rows), int(cols), int(channels), encoding.encode(), C.byref(tr), C.byref(tc), C.byref(tcn))
+        return tr.value, tc.value, tcn.value
+
     def process(self, image, encoding):
         """cv::Mat process(const cv::Mat&, std::string&): returns a new array; input untouched."""
         img = np.asarray(image)
@@ -171,6 +210,7 @@ class RawImagePipeline:
         out = np.empty(orows * ocols * ocn, np.uint16 if wide else np.uint8)
         r, c, k = C.c_int(), C.c_int(), C.c_int()
         enc = C.create_string_buffer(32)
+        self._given_last = (None, None, None)  # the image getters now belong to this frame
         self._call("rip_apply", img.ctypes.data_as(C.c_void_p), rows, cols, cn, C.c_size_t(img.strides[0]),
                    encoding.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes), C.byref(r), C.byref(c),
                    C.byref(k), enc)
@@ -186,9 +226,13 @@ class RawImagePipeline:
         return out
 
     # ---- asynchronous host frames (rip_submit / rip_collect; no counterpart in the reference's binding) -------------
-    def submit(self, image, encoding):
+    def submit(self, image, encoding, out=None, tap_debayered=None, tap_color=None):
         """Enqueues upload + chain + download of one host frame and returns its ticket without waiting (rip_submit).  Up to
-        ``set_ring_depth`` (default 3) frames may be in flight; frames are processed in submission order."""
+        ``set_ring_depth`` (default 3) frames may be in flight; frames are processed in submission order.
+
+        ``out`` / ``tap_debayered`` / ``tap_color``: page-locked arrays (``host_alloc``, a pinned ``OutputPool``) of the
+        result's / the taps' shape -- the downloads are written straight into them (rip_submit_to) and ``collect`` / the image
+        getters return these very arrays: deep-copy semantics without a copy."""
         img = np.asarray(image)
         if img.dtype not in (np.uint8, np.uint16) or img.ndim not in (2, 3):
             raise ValueError("image must be uint8 (or uint16 Bayer), HxW or HxWxC")
@@ -197,7 +241,19 @@ class RawImagePipeline:
         rows, cols = img.shape[:2]
         cn = 1 if img.ndim == 2 else img.shape[2]
         t = C.c_uint64()
-        self._call("rip_submit", img.ctypes.data_as(C.c_void_p), rows, cols, cn, C.c_size_t(img.strides[0]), encoding.encode(), C.byref(t))
+        given = (out, tap_debayered, tap_color)
+        if all(g is None for g in given):
+            self._call("rip_submit", img.ctypes.data_as(C.c_void_p), rows, cols, cn, C.c_size_t(img.strides[0]), encoding.encode(), C.byref(t))
+            return t.value
+        for g in given:
+            if g is not None and not (isinstance(g, np.ndarray) and g.flags.c_contiguous and g.flags.writeable):
+                raise ValueError("out / tap arrays must be writeable C-contiguous numpy arrays over page-locked memory")
+        ptr = lambda g: g.ctypes.data_as(C.c_void_p) if g is not None else None
+        taps = [g for g in (tap_debayered, tap_color) if g is not None]
+        self._call("rip_submit_to", img.ctypes.data_as(C.c_void_p), rows, cols, cn, C.c_size_t(img.strides[0]), encoding.encode(),
+                   ptr(out), C.c_size_t(out.nbytes if out is not None else 0), ptr(tap_debayered), ptr(tap_color),
+                   C.c_size_t(min(g.nbytes for g in taps) if taps else 0), C.byref(t))
+        self._given[t.value] = given
         return t.value
 
     def collect(self, ticket, copy=True):
@@ -213,8 +269,13 @@ class RawImagePipeline:
         wide = self.last_encoding.endswith("16")
         n = r.value * c.value * k.value
         shape = (r.value, c.value) if k.value == 1 else (r.value, c.value, k.value)
+        self._given_last = self._given.pop(int(ticket), (None, None, None))
+        if self._given_last[0] is not None:  # the download went straight into the caller's array: it IS the deep copy
+            g = self._given_last[0]
+            return g if g.shape == tuple(shape) else g.reshape(shape)
         if copy:  # the library's copy (split over a few threads for whole frames), not numpy's
-            out = np.empty(shape, np.uint16 if wide else np.uint8)
+            dtype = np.uint16 if wide else np.uint8
+            out = self.out_pool.take(shape, dtype) if self.out_pool is not None else np.empty(shape, dtype)
             self._lib.rip_copy_host(out.ctypes.data_as(C.c_void_p), view, C.c_size_t(out.nbytes))
             return out
         buf = (C.c_uint16 if wide else C.c_uint8) * n
@@ -270,6 +331,7 @@ class RawImagePipeline:
                 if t is not None:
                     t.record_stream(mine)
         with torch.cuda.device(frames.device):  # the C-ABI selects the handle's device; keep the caller's current device
+            self._given_last = (None, None, None)
             self._call("rip_apply_device", C.c_void_p(frames.data_ptr()), C.c_size_t(in_step), C.c_size_t(in_frame), int(n),
                        int(rows), int(cols), int(cn), encoding.encode(), C.c_void_p(out.data_ptr()), C.c_size_t(0),
                        C.c_size_t(0), C.c_void_p(tap_debayered.data_ptr() if tap_debayered is not None else 0),
@@ -290,6 +352,9 @@ class RawImagePipeline:
         (rip_get_image_view; same lifetime as ``collect(copy=False)``); frames of ``process`` only exist on the device and are
         copied as before."""
         r, c, k = C.c_int(), C.c_int(), C.c_int()
+        given = {IMAGE_DEBAYERED: self._given_last[1], IMAGE_COLOR: self._given_last[2], IMAGE_PROCESSED: self._given_last[0]}.get(which)
+        if given is not None:  # the tap of the collected frame was downloaded into the caller's own array (submit(..., tap_*=))
+            return given
         if not copy:
             view = C.c_void_p()
             self._call("rip_get_image_view", which, C.byref(view), C.byref(r), C.byref(c), C.byref(k))
@@ -302,10 +367,11 @@ class RawImagePipeline:
         self._call("rip_get_image", which, None, C.c_size_t(0), C.byref(r), C.byref(c), C.byref(k))
         if r.value == 0 or c.value == 0:
             return np.empty((0, 0), np.uint8)
-        out = np.empty(r.value * c.value * k.value, np.uint8)
+        shape = (r.value, c.value) if k.value == 1 else (r.value, c.value, k.value)
+        out = self.out_pool.take(shape) if self.out_pool is not None else np.empty(shape, np.uint8)
         self._call("rip_get_image", which, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(r), C.byref(c),
                    C.byref(k))
-        return out.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
+        return out
 
     def get_dist_debayered_image(self, copy=True):
         return self._get_image(IMAGE_DEBAYERED, copy)

@@ -301,3 +301,28 @@ def test_bench_without_a_gpu_exits_loudly_and_prints_no_line():
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "MI355X" in r.stderr
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_output_pool_recycles_only_arrays_nobody_references():
+    """OutputPool (the destination arrays of the front end's deep copies): an array is handed out again only when the pool's
+    own list is its last reference -- a caller's variable, a message holding it, a VIEW of it (its base) all keep it out."""
+    from raw_image_pipeline_amd import OutputPool
+    pool = OutputPool(limit=3)
+    a = pool.take((4, 5, 3))
+    b = pool.take((4, 5, 3))
+    assert b is not a and a.shape == (4, 5, 3) and a.dtype == np.uint8
+    a_id = id(a)
+    held = {"image": b}          # e.g. a published message
+    del b
+    view = a[::2]                # a view keeps its base alive
+    del a
+    c = pool.take((4, 5, 3))
+    assert not np.shares_memory(c, view) and not np.shares_memory(c, held["image"])
+    del view
+    d = pool.take((4, 5, 3))     # the first array is free again
+    assert id(d) == a_id
+    other = pool.take((2, 2), np.uint16)
+    assert other.dtype == np.uint16 and other.shape == (2, 2)
+    many = [pool.take((4, 5, 3)) for _ in range(6)]   # more than the limit in use at once: plain allocations, never shared
+    assert len({id(m) for m in many}) == 6
+    assert len(pool._arrays[((4, 5, 3), np.dtype(np.uint8).str)]) <= 3

@@ -726,6 +726,55 @@ def test_debug_stage_dumps_do_not_advance_the_ccc_filter_and_handle_mono(rip_lib
 
 
 @pytest.mark.gpu
+def test_submit_to_downloads_into_the_callers_page_locked_arrays(rip_lib, oracle):
+    """rip_submit_to: the caller names the destination of the result and of the taps -- page-locked arrays the downloads are
+    written into directly; collect() and the image getters return those very arrays (the deep copies the reference's
+    process() / getters hand out, raw_image_pipeline.cpp:182-236, without a copy).  Same pixels as the oracle; frames with
+    and without destinations interleave; a pageable, a too small or an unkept-tap destination is refused before anything is
+    enqueued."""
+    from raw_image_pipeline_amd import OutputPool, RawImagePipeline, TAP_COLOR, TAP_DEBAYERED, TAP_PROCESSED
+    from raw_image_pipeline_amd.pipeline import host_alloc
+    w, h = 640, 480
+    pipe = RawImagePipeline(False, "", "", "", device=0)
+    c = cfg(flip=True, flip_angle=180, wb=True, wb_method="gray_world", cc=True, gamma=True, gamma_k=0.8, undistort=True, cam=synth.camera_model(w, h))
+    configure(pipe, c)
+    pipe.set_taps(TAP_PROCESSED | TAP_COLOR | TAP_DEBAYERED)
+    frames = [synth.gen_frame(w, h, "bayer_rggb8", seed=9500 + i, kind="scene") for i in range(6)]
+    refs = [oracle_run(oracle, c, f, "bayer_rggb8", taps=True) for f in frames]
+    pool = OutputPool(limit=12, pinned=True)
+    pending = []
+    for i, f in enumerate(frames):
+        if i % 3 == 2:   # a frame without destinations in between: the handle's own buffers
+            pending.append((i, pipe.submit(f, "bayer_rggb8"), None))
+        else:
+            dst = dict(out=pool.take((h, w, 3)), tap_debayered=pool.take((h, w, 3)), tap_color=pool.take((h, w, 3)) if i % 2 else None)
+            pending.append((i, pipe.submit(f, "bayer_rggb8", **{k: v for k, v in dst.items() if v is not None}), dst))
+        if len(pending) == 2:
+            j, t, dst = pending.pop(0)
+            got = pipe.collect(t)
+            assert_images_equal(got, refs[j][0], "frame %d result" % j)
+            assert_images_equal(pipe.get_dist_debayered_image(), refs[j][2].reshape(h, w, 3), "frame %d debayered tap" % j)
+            assert_images_equal(pipe.get_dist_color_image(), refs[j][3].reshape(h, w, 3), "frame %d colour tap" % j)
+            if dst is not None:
+                assert got is dst["out"] and pipe.get_dist_debayered_image() is dst["tap_debayered"]
+                assert (pipe.get_dist_color_image() is dst["tap_color"]) == (dst["tap_color"] is not None)
+    for j, t, dst in pending:
+        assert_images_equal(pipe.collect(t), refs[j][0], "tail frame %d" % j)
+    # a synchronous frame afterwards: the getters belong to it again
+    assert_images_equal(pipe.process(frames[0], "bayer_rggb8"), refs[0][0], "process() after the ring")
+    assert_images_equal(pipe.get_dist_color_image(), refs[0][3].reshape(h, w, 3), "tap of process()")
+    # refusals: nothing is enqueued, the ring stays usable
+    with pytest.raises(ValueError, match="page-locked"):
+        pipe.submit(frames[0], "bayer_rggb8", out=np.empty((h, w, 3), np.uint8))
+    with pytest.raises(RipError, match="too small"):
+        pipe.submit(frames[0], "bayer_rggb8", out=host_alloc((h // 2, w, 3)))
+    pipe.set_taps(TAP_PROCESSED)
+    with pytest.raises(ValueError, match="not kept"):
+        pipe.submit(frames[0], "bayer_rggb8", out=host_alloc((h, w, 3)), tap_color=host_alloc((h, w, 3)))
+    assert_images_equal(pipe.collect(pipe.submit(frames[1], "bayer_rggb8", out=host_alloc((h, w, 3)))), refs[1][0], "after the refusals")
+
+
+@pytest.mark.gpu
 def test_a_deeper_ring_is_not_slower(rip_lib):
     """More than three host frames enqueued on one device -- a ring deeper than the default, or several handles -- made every
     other 15 MB download take 1.2 ms or more instead of 0.3 (the runtime's handling of SDMA copies behind cross-stream waits),
