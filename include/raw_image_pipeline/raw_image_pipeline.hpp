@@ -142,6 +142,19 @@ class RawImagePipeline {
     check(rip_submit(h_, detail::bytes(image), image.rows, image.cols, image.channels(), detail::step_of(image), encoding.c_str(), &ticket));
     return ticket;
   }
+  // submit() with the destinations named by the caller (rip_submit_to): `out` -- and the taps the object keeps, when given --
+  // are continuous Mats over PAGE-LOCKED memory (rip_host_alloc, cv::cuda::HostMem, cudaHostRegister'ed pages) of the
+  // result's / the taps' size; the downloads are written into them directly and collectView() / the *View() getters return
+  // headers over these very buffers: the clone the reference hands out without a copy.  They must stay untouched until the
+  // ticket is collected.
+  uint64_t submitTo(const Mat& image, const std::string& encoding, Mat& out, Mat* tap_debayered = nullptr, Mat* tap_color = nullptr) {
+    uint64_t ticket = 0;
+    const Mat* tap = tap_debayered ? tap_debayered : tap_color;
+    check(rip_submit_to(h_, detail::bytes(image), image.rows, image.cols, image.channels(), detail::step_of(image), encoding.c_str(),
+                        detail::bytes(out), (size_t)out.rows * out.cols * out.channels(), tap_debayered ? detail::bytes(*tap_debayered) : nullptr,
+                        tap_color ? detail::bytes(*tap_color) : nullptr, tap ? (size_t)tap->rows * tap->cols * tap->channels() : 0, &ticket));
+    return ticket;
+  }
   Mat collect(uint64_t ticket, std::string& encoding) {
     // the clone the reference's process() / getters promise, through the library's split copy (rip_copy_host): a 15 MB
     // Mat::clone() on one thread takes longer than the frame's kernels and PCIe transfers together

@@ -13,9 +13,11 @@ using raw_image_pipeline::RawImagePipeline;
 // cv::Mat(rows, cols, type) with OpenCV headers, the stand-in's (rows, cols, channels) without
 #ifdef RIP_HAVE_OPENCV
 static Mat make_u8(int rows, int cols, int channels) { return Mat(rows, cols, CV_8UC(channels)); }
+static Mat wrap_u8(int rows, int cols, int channels, uint8_t* ptr) { return Mat(rows, cols, CV_8UC(channels), ptr); }
 typedef cv::Exception AssertType;
 #else
 static Mat make_u8(int rows, int cols, int channels) { return Mat(rows, cols, channels); }
+static Mat wrap_u8(int rows, int cols, int channels, uint8_t* ptr) { return Mat(rows, cols, channels, ptr); }
 typedef raw_image_pipeline::AssertionError AssertType;
 #endif
 
@@ -106,6 +108,23 @@ int main(int argc, char** argv) {
       return fail("ticket collected twice");
     } catch (const std::invalid_argument&) {
     }
+    // submitTo(): the result and the colour tap land in page-locked memory of the caller's
+    uint8_t* pin_out = static_cast<uint8_t*>(rip_host_alloc((size_t)w * h * 3));
+    uint8_t* pin_col = static_cast<uint8_t*>(rip_host_alloc((size_t)w * h * 3));
+    if (!pin_out || !pin_col) return fail("rip_host_alloc");
+    Mat mo = wrap_u8(h, w, 3, pin_out), mc = wrap_u8(h, w, 3, pin_col);
+    std::string e3;
+    Mat v3 = proc.collectView(proc.submitTo(bayer, "bayer_rggb8", mo, nullptr, &mc), e3);
+    if (v3.data != pin_out || std::memcmp(pin_out, out.data, (size_t)w * h * 3) != 0) return fail("submitTo result");
+    if (proc.getDistColorImageView().data != pin_col || std::memcmp(pin_col, col.data, (size_t)w * h * 3) != 0) return fail("submitTo colour tap");
+    try {  // a pageable destination is refused
+      Mat pageable = make_u8(h, w, 3);
+      proc.submitTo(bayer, "bayer_rggb8", pageable);
+      return fail("pageable destination accepted");
+    } catch (const std::invalid_argument&) {
+    }
+    rip_host_free(pin_out);
+    rip_host_free(pin_col);
   }
   try {  // cvtColor(BGR2Lab) on one channel: cv::Exception with OpenCV, AssertionError without
     Mat mono = make_u8(h, w, 1);
