@@ -209,6 +209,10 @@ struct InflightGate {
   void admit(int device) {
     const int c = cap();
     if (c <= 0) return;
+    // The wait happens under the lock on purpose: an event in the queue belongs to some handle's slot, and forget() --
+    // called before a slot's events are destroyed or recorded again -- must not get past it while it is waited on.  The wait
+    // is for a frame that is already enqueued in full (at most one frame time), and whoever else wants the lock meanwhile is
+    // either about to wait for the same frame (another submit at the limit) or finishes a collect a moment later.
     std::lock_guard<std::mutex> lk(mu);
     auto& d = q[device & 63];
     while ((int)d.size() >= c) {
