@@ -67,13 +67,13 @@ class CameraStream:
         self._skipped_rect = 0  # skipped_images_for_slow_topic_rect_
         # raw_image_pipeline_ = std::make_unique<RawImagePipeline>(use_gpu)  (:52): the one-argument constructor
         self.pipe = pipeline if pipeline is not None else RawImagePipeline(bool(p["use_gpu"]), device=device)
+        # The published images are deep copies (the reference clones every one, raw_image_pipeline.cpp:222-236).  Their arrays
+        # are recycled once the subscriber has dropped them -- a fresh 15 MB array costs more than filling it -- and they are
+        # page-locked: the synchronous path downloads into them at the full PCIe rate, and on the pipelined path the downloads
+        # are written into them directly (rip_submit_to): no pinned buffer of the handle in between, no memcpy at collect()
         if self.pipe.out_pool is None:
-            # the published images are deep copies (the reference clones every one, raw_image_pipeline.cpp:222-236); their
-            # arrays are recycled once the subscriber has dropped them -- a fresh 15 MB array costs more than filling it
-            self.pipe.out_pool = OutputPool()
-        # ... and on the pipelined path they are page-locked arrays the downloads are written into directly (rip_submit_to):
-        # no pinned buffer of the handle in between, no memcpy at collect()
-        self._pinned_pool = OutputPool(limit=12, pinned=True)
+            self.pipe.out_pool = OutputPool(limit=16, pinned=True)
+        self._pinned_pool = self.pipe.out_pool if self.pipe.out_pool.pinned else None
         self._configure()
         if ccc_model is not None:
             self.pipe.set_ccc_model(*ccc_model)
@@ -179,12 +179,12 @@ class CameraStream:
             cn = 1 if img.ndim == 2 else img.shape[2]
             r, c, k, enc_out = self.pipe.query_output(rows, cols, cn, encoding)
             if not enc_out.endswith("16"):
-                dst["out"] = self._pinned_pool.take((r, c) if k == 1 else (r, c, k))
+                dst["out"] = self._pinned_pool.take((r, c) if k == 1 else (r, c, k), or_none=True)
                 tr, tc, tk = self.pipe.query_taps(rows, cols, cn, encoding)
                 if self._tap_mask & TAP_DEBAYERED:
-                    dst["tap_debayered"] = self._pinned_pool.take((tr, tc) if tk == 1 else (tr, tc, tk))
+                    dst["tap_debayered"] = self._pinned_pool.take((tr, tc) if tk == 1 else (tr, tc, tk), or_none=True)
                 if self._tap_mask & TAP_COLOR:
-                    dst["tap_color"] = self._pinned_pool.take((tr, tc) if tk == 1 else (tr, tc, tk))
+                    dst["tap_color"] = self._pinned_pool.take((tr, tc) if tk == 1 else (tr, tc, tk), or_none=True)
         ticket = self.pipe.submit(img, encoding, **{key: arr for key, arr in dst.items() if arr is not None})
         self._inflight = getattr(self, "_inflight", [])
         self._inflight.append((ticket, stamp, frame_id))

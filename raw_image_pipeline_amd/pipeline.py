@@ -100,7 +100,10 @@ class OutputPool:
         self._arrays = {}
         self._refcount = getattr(sys, "getrefcount", None)
 
-    def take(self, shape, dtype=np.uint8):
+    def take(self, shape, dtype=np.uint8, or_none=False):
+        """An array of this shape nobody else references.  A pinned pool whose ``limit`` arrays are all in use hands out an
+        ordinary array (page-locked memory is only worth its allocation when it is recycled) -- or None with ``or_none``,
+        for callers that need the page lock (``submit(..., out=)``)."""
         key = (tuple(shape), np.dtype(dtype).str)
         arrays = self._arrays.setdefault(key, [])
         if self._refcount is not None:
@@ -109,7 +112,7 @@ class OutputPool:
                 if self._refcount(arrays[i]) == 2:
                     return arrays[i]
         if self.pinned and not (self._refcount is not None and len(arrays) < self.limit):
-            return None  # page-locked memory is only worth its allocation when it is recycled: the caller copies instead
+            return None if or_none else np.empty(shape, dtype)
         arr = host_alloc(shape, dtype) if self.pinned else np.empty(shape, dtype)
         if self._refcount is not None and len(arrays) < self.limit:
             arrays.append(arr)
@@ -207,7 +210,9 @@ class RawImagePipeline:
         orows, ocols, ocn, oenc = self.query_output(rows, cols, cn, encoding)
         if wide != oenc.endswith("16"):
             raise ValueError("dtype %s does not match encoding %s" % (img.dtype, encoding))
-        out = np.empty(orows * ocols * ocn, np.uint16 if wide else np.uint8)
+        oshape = (orows, ocols) if ocn == 1 else (orows, ocols, ocn)
+        odtype = np.uint16 if wide else np.uint8
+        out = self.out_pool.take(oshape, odtype) if self.out_pool is not None else np.empty(oshape, odtype)
         r, c, k = C.c_int(), C.c_int(), C.c_int()
         enc = C.create_string_buffer(32)
         self._given_last = (None, None, None)  # the image getters now belong to this frame
@@ -215,7 +220,8 @@ class RawImagePipeline:
                    encoding.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes), C.byref(r), C.byref(c),
                    C.byref(k), enc)
         self.last_encoding = enc.value.decode()
-        return out.reshape((r.value, c.value) if k.value == 1 else (r.value, c.value, k.value))
+        shape = (r.value, c.value) if k.value == 1 else (r.value, c.value, k.value)
+        return out if out.shape == shape else out.reshape(shape)
 
     def apply(self, image, encoding):
         """bool apply(cv::Mat&, std::string&): returns the processed image; when it has the input's
