@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,8 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+
+#include <pthread.h>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -136,7 +139,8 @@ class CopyPool {
     return *pool;
   }
   void copy(void* dst, const void* src, size_t bytes) {
-    if (bytes < (size_t(4) << 20) || workers_ == 0 || !busy_.try_lock()) {
+    // a forked child has none of the worker threads and may have inherited the mutexes locked: plain memcpy there
+    if (bytes < (size_t(4) << 20) || workers_ == 0 || forked().load(std::memory_order_relaxed) || !busy_.try_lock()) {
       std::memcpy(dst, src, bytes);
       return;
     }
@@ -155,7 +159,12 @@ class CopyPool {
   }
 
  private:
+  static std::atomic<bool>& forked() {
+    static std::atomic<bool> f{false};
+    return f;
+  }
   CopyPool() {
+    (void)pthread_atfork(nullptr, nullptr, [] { forked().store(true, std::memory_order_relaxed); });
     const char* e = std::getenv("RIP_COPY_THREADS");  // worker threads beside the caller; 0 = plain memcpy
     const int hw = (int)std::thread::hardware_concurrency();
     workers_ = e ? std::max(0, std::min(16, std::atoi(e))) : std::max(0, std::min(3, hw - 1));

@@ -94,3 +94,36 @@ def test_copy_host_copies_every_size_and_survives_concurrent_callers(rip_lib):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_copy_host_in_a_forked_child_copies_on_its_own_thread(rip_lib):
+    """The copy pool's worker threads do not exist in a forked child (and its mutexes may have been inherited locked): the
+    child's rip_copy_host must fall back to a plain memcpy instead of waiting for workers."""
+    import ctypes as C
+    import os
+    import numpy as np
+    lib = rip_lib
+    lib.rip_copy_host.restype = None
+    lib.rip_copy_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    src = np.random.default_rng(1).integers(0, 256, 9 << 20, dtype=np.uint8)
+    dst = np.empty_like(src)
+    lib.rip_copy_host(dst.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), C.c_size_t(src.size))  # the pool exists now
+    assert np.array_equal(dst, src)
+    pid = os.fork()
+    if pid == 0:
+        out = np.empty_like(src)
+        lib.rip_copy_host(out.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), C.c_size_t(src.size))
+        os._exit(0 if np.array_equal(out, src) else 1)
+    deadline = 30.0
+    import time
+    t0 = time.time()
+    while True:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        if time.time() - t0 > deadline:
+            os.kill(pid, 9)
+            os.waitpid(pid, 0)
+            raise AssertionError("the forked child hung in rip_copy_host")
+        time.sleep(0.05)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
