@@ -105,7 +105,13 @@ class OutputPool:
         ordinary array (page-locked memory is only worth its allocation when it is recycled) -- or None with ``or_none``,
         for callers that need the page lock (``submit(..., out=)``)."""
         key = (tuple(shape), np.dtype(dtype).str)
-        arrays = self._arrays.setdefault(key, [])
+        if key not in self._arrays and len(self._arrays) >= 4:
+            # a camera whose image size keeps changing must not pile up page-locked memory: forget the arrays of the shapes
+            # seen longest ago (whoever still holds one of them keeps it alive; it just is not recycled any more)
+            for old in list(self._arrays)[:len(self._arrays) - 3]:
+                del self._arrays[old]
+        arrays = self._arrays.pop(key, [])
+        self._arrays[key] = arrays  # most recently used last
         if self._refcount is not None:
             for i in range(len(arrays)):
                 # references: the list, the call argument of getrefcount -- anything above is somebody else's
