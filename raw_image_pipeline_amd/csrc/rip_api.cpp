@@ -125,8 +125,6 @@ struct Plan {
   std::string encoding_out;
 };
 
-// One frame in flight on the asynchronous host path (rip_submit / rip_collect): its own device input / output / tap
-// buffers, a pinned result buffer, and the three events that chain upload -> kernels -> download.
 // Host-side copies of whole frames (the deep copies the reference's API promises: process() and every image getter return a
 // clone, raw_image_pipeline.cpp:182-236): a 15 MB memcpy out of the pinned result buffer into freshly allocated pages takes
 // 0.4-0.7 ms on one thread -- more than the frame's kernels and its PCIe transfer together -- so copies of 4 MB and more are
@@ -247,6 +245,8 @@ InflightGate& inflight_gate() {
   return g;
 }
 
+// One frame in flight on the asynchronous host path (rip_submit / rip_collect): its own device input / output / tap
+// buffers, a pinned result buffer, and the three events that chain upload -> kernels -> download.
 struct RingSlot {
   DevBuf d_in, d_out, d_tap_deb, d_tap_col;
   void* h_out = nullptr;  // hipHostMalloc
