@@ -321,7 +321,8 @@ enum {
   RIP_PROBE_EXPAND13_NT = 4, /* the same with non-temporal stores (how the chain writes an image nothing reads again) */
   RIP_PROBE_COPY12 = 5,      /* 12 B per lane in and out: the remap's store shape fed by a contiguous read */
   RIP_PROBE_EXPAND13_WIDE = 6,    /* 16 B per lane in, 48 contiguous B out (three 16-byte stores) */
-  RIP_PROBE_EXPAND13_WIDE_NT = 7  /* the same with non-temporal stores */
+  RIP_PROBE_EXPAND13_WIDE_NT = 7, /* the same with non-temporal stores */
+  RIP_PROBE_READ_NT = 8           /* read only, eight 16-byte non-temporal loads in flight per lane */
 };
 rip_status rip_debug_hbm_probe(rip_pipeline* p, int kind, size_t bytes, int reps, double* gbps);
 const char* rip_version(void);

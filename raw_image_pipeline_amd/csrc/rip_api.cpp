@@ -2129,7 +2129,7 @@ rip_status rip_debug_hbm_probe(rip_pipeline* p, int kind, size_t bytes, int reps
   return guarded(p, [&] {
     need_device(p);
     if (!gbps) throw InvalidArgument("null result pointer");
-    if (kind < RIP_PROBE_COPY || kind > RIP_PROBE_EXPAND13_WIDE_NT) throw InvalidArgument("unknown probe kind");
+    if (kind < RIP_PROBE_COPY || kind > RIP_PROBE_READ_NT) throw InvalidArgument("unknown probe kind");
     bytes = bytes / 48 * 48;
     if (bytes < 48 || reps < 1) throw InvalidArgument("rip_debug_hbm_probe: at least 48 bytes and one repetition");
     DeviceGuard device_guard(p->device);
