@@ -322,7 +322,9 @@ enum {
   RIP_PROBE_COPY12 = 5,      /* 12 B per lane in and out: the remap's store shape fed by a contiguous read */
   RIP_PROBE_EXPAND13_WIDE = 6,    /* 16 B per lane in, 48 contiguous B out (three 16-byte stores) */
   RIP_PROBE_EXPAND13_WIDE_NT = 7, /* the same with non-temporal stores */
-  RIP_PROBE_READ_NT = 8           /* read only, eight 16-byte non-temporal loads in flight per lane */
+  RIP_PROBE_READ_NT = 8,          /* read only, eight 16-byte non-temporal loads in flight per lane */
+  RIP_PROBE_EXPAND13_COALESCED = 9,    /* 16 B per lane in, three 16-byte stores out, each store instruction of a wave contiguous (1 KB) */
+  RIP_PROBE_EXPAND13_COALESCED_NT = 10 /* the same with non-temporal stores */
 };
 rip_status rip_debug_hbm_probe(rip_pipeline* p, int kind, size_t bytes, int reps, double* gbps);
 const char* rip_version(void);

@@ -2129,12 +2129,14 @@ rip_status rip_debug_hbm_probe(rip_pipeline* p, int kind, size_t bytes, int reps
   return guarded(p, [&] {
     need_device(p);
     if (!gbps) throw InvalidArgument("null result pointer");
-    if (kind < RIP_PROBE_COPY || kind > RIP_PROBE_READ_NT) throw InvalidArgument("unknown probe kind");
+    if (kind < RIP_PROBE_COPY || kind > RIP_PROBE_EXPAND13_COALESCED_NT) throw InvalidArgument("unknown probe kind");
     bytes = bytes / 48 * 48;
+    if (kind == RIP_PROBE_EXPAND13_COALESCED || kind == RIP_PROBE_EXPAND13_COALESCED_NT) bytes = bytes / 3072 * 3072;  // whole waves of 16-byte lanes
     if (bytes < 48 || reps < 1) throw InvalidArgument("rip_debug_hbm_probe: at least 48 bytes and one repetition");
     DeviceGuard device_guard(p->device);
     DevBuf src, dst;
-    const bool expands = kind == RIP_PROBE_EXPAND13 || kind == RIP_PROBE_EXPAND13_NT || kind == RIP_PROBE_EXPAND13_WIDE || kind == RIP_PROBE_EXPAND13_WIDE_NT;
+    const bool expands = kind == RIP_PROBE_EXPAND13 || kind == RIP_PROBE_EXPAND13_NT || kind == RIP_PROBE_EXPAND13_WIDE || kind == RIP_PROBE_EXPAND13_WIDE_NT ||
+                         kind == RIP_PROBE_EXPAND13_COALESCED || kind == RIP_PROBE_EXPAND13_COALESCED_NT;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     try {
       if (kind != RIP_PROBE_FILL) {

@@ -93,6 +93,24 @@ __global__ __launch_bounds__(kProbeBlock) void probe_expand13_wide_kernel(const 
     dst[3 * i + 2] = c;
   }
 }
+// the same byte ratio with every store instruction of a wave covering 1 KB of contiguous bytes (what a kernel that transposes
+// its output through LDS or lane shuffles would issue): is the 1 : 3 rate a property of the ratio or of the 12 / 48-byte lanes?
+__global__ __launch_bounds__(kProbeBlock) void probe_expand13_coalesced_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16, int nt) {
+  const size_t i = (size_t)blockIdx.x * kProbeBlock + threadIdx.x;
+  if (i >= n16) return;
+  const u32x4 v = src[i];
+  const u32x4 a = {v.x, v.x ^ 1u, v.x ^ 2u, v.y}, b = {v.y ^ 1u, v.y ^ 2u, v.z, v.z ^ 1u}, c = {v.z ^ 2u, v.w, v.w ^ 1u, v.w ^ 2u};
+  u32x4* out = dst + 3 * (i & ~(size_t)63) + (i & 63);  // the wave's 3 KB: three runs of 64 x 16 bytes
+  if (nt) {
+    __builtin_nontemporal_store(a, out);
+    __builtin_nontemporal_store(b, out + 64);
+    __builtin_nontemporal_store(c, out + 128);
+  } else {
+    out[0] = a;
+    out[64] = b;
+    out[128] = c;
+  }
+}
 // 3 : 3 copy in 12-byte lanes: the remap's store shape fed by a contiguous read (its gather replaced by a stream)
 __global__ __launch_bounds__(kProbeBlock) void probe_copy12_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n12) {
   const size_t i = (size_t)blockIdx.x * kProbeBlock + threadIdx.x;
@@ -128,6 +146,12 @@ size_t launch_hbm_probe(int kind, const void* src, void* dst, size_t bytes, hipS
     case 7:
       hipLaunchKernelGGL(probe_expand13_wide_kernel, blocks(bytes / 16), dim3(kProbeBlock), 0, stream, static_cast<const u32x4*>(src), static_cast<u32x4*>(dst), bytes / 16,
                          kind == 7 ? 1 : 0);
+      return 4 * (bytes / 16 * 16);
+    case 9:
+    case 10:
+      if ((bytes / 16) % 64) return 0;  // whole waves only
+      hipLaunchKernelGGL(probe_expand13_coalesced_kernel, blocks(bytes / 16), dim3(kProbeBlock), 0, stream, static_cast<const u32x4*>(src), static_cast<u32x4*>(dst),
+                         bytes / 16, kind == 10 ? 1 : 0);
       return 4 * (bytes / 16 * 16);
     case 8:
       hipLaunchKernelGGL(probe_read_nt_kernel, blocks((bytes / 16 + kReadUnrollNt - 1) / kReadUnrollNt), dim3(kProbeBlock), 0, stream, static_cast<const u32x4*>(src),

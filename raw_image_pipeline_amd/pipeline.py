@@ -665,7 +665,7 @@ class RawImagePipeline:
         overrides once, when the handle is created)."""
         self._call("rip_set_tunable", name.encode(), int(value))
 
-    PROBE_KINDS = {"copy": 0, "read": 1, "fill": 2, "expand13": 3, "expand13_nt": 4, "copy12": 5, "expand13_wide": 6, "expand13_wide_nt": 7, "read_nt": 8}
+    PROBE_KINDS = {"copy": 0, "read": 1, "fill": 2, "expand13": 3, "expand13_nt": 4, "copy12": 5, "expand13_wide": 6, "expand13_wide_nt": 7, "read_nt": 8, "expand13_coalesced": 9, "expand13_coalesced_nt": 10}
 
     def hbm_probe(self, kind, nbytes=1 << 30, reps=10):
         """GB/s (best of ``reps`` launches, bytes read + written) of one of the library's hand-written streaming kernels on
