@@ -323,7 +323,7 @@ def hbm_probe(pipe, torch, nbytes=1 << 30, reps=10):
     (four loads in flight per lane; eight with the non-temporal hint), fill, the chain's 1 : 3 expand with ordinary and non-temporal stores, a 12-byte-lane copy) -- and, for continuity with the
     round-1..3 lines, torch's elementwise copy_ and sum, which run 15-20 % below them."""
     res = {}
-    for kind in ("copy", "read", "read_nt", "fill", "expand13", "expand13_nt", "expand13_wide", "expand13_wide_nt", "copy12"):
+    for kind in ("copy", "read", "read_nt", "fill", "expand13", "expand13_nt", "expand13_wide", "expand13_wide_nt", "expand13_coalesced", "copy12"):
         try:
             res[kind + "_GBps"] = round(pipe.hbm_probe(kind, nbytes, reps), 1)
         except Exception as e:  # noqa: BLE001 -- the bench line must come out whatever a probe does
