@@ -1061,3 +1061,30 @@ def test_undistortion_alone_gathers_from_the_input_frames(gpu_pipe, oracle, enco
         ref, _ = oracle_run(oracle, c, frames[i], encoding)
         assert_images_equal(out[i].reshape(ref.shape), ref, "%s direct remap frame %d" % (encoding, i))
     run_both(gpu_pipe, oracle, c, frames[0], encoding, TOL_INTERP, what="%s undistortion only, host frame" % encoding)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoding,angle,gamma", [("mono8", 180, True), ("mono8", 0, True), ("mono8", 180, False), ("bayer_grbg8", 180, True), ("bayer_rggb8", 0, False)])
+@pytest.mark.parametrize("w,pitch", [(1000, 1008), (644, 656), (2448, 2464)])
+def test_chain_skipping_paths_on_pitched_resident_frames(gpu_pipe, oracle, encoding, angle, gamma, w, pitch):
+    """The paths that run the chain inside the gather (mono8: flip + gamma table in the one-channel ring remap; Bayer: the
+    chain inside the remap's tiles) stage source rectangles from 16-byte-aligned columns of the caller's frames: resident
+    frames whose row pitch is a multiple of 16 while their width is not (1000 / 1008, 644 / 656) or with padding behind
+    every row (2448 / 2464) must give the oracle's pixels -- the rectangle's phase inside its first 16-byte chunk, the mirrored
+    addressing under the 180-degree flip and the frame's readable extent all depend on the pitch."""
+    import torch
+    h = 120 if w != 2448 else 200
+    c = cfg(flip=angle != 0, flip_angle=angle, gamma=gamma, gamma_k=0.8, undistort=True, cam=synth.camera_model(w, h), balance=0.3, fov_scale=1.1)
+    configure(gpu_pipe, c)
+    n = 5
+    frames = [synth.gen_frame(w, h, "bayer_rggb8", seed=9700 + i, kind="scene" if i % 2 else "uniform") for i in range(n)]
+    padded = torch.full((n, h, pitch), 0xA5, dtype=torch.uint8, device="cuda")
+    view = padded[:, :, :w]
+    view.copy_(torch.from_numpy(np.stack(frames)).cuda())
+    gpu_pipe.profile_begin(16)
+    out = gpu_pipe.apply_device(view, encoding).cpu().numpy()
+    prof = gpu_pipe.profile_end()
+    assert prof["chain"][1] == 0, "a 16-byte-aligned pitch must take the chain-skipping path: %s" % (prof,)
+    for i in range(n):
+        ref, _ = oracle_run(oracle, c, frames[i], encoding)
+        assert_images_equal(out[i].reshape(ref.shape), ref, "%s pitched %d/%d frame %d" % (encoding, w, pitch, i))
