@@ -1088,3 +1088,42 @@ def test_chain_skipping_paths_on_pitched_resident_frames(gpu_pipe, oracle, encod
     for i in range(n):
         ref, _ = oracle_run(oracle, c, frames[i], encoding)
         assert_images_equal(out[i].reshape(ref.shape), ref, "%s pitched %d/%d frame %d" % (encoding, w, pitch, i))
+
+
+@pytest.mark.gpu
+def test_ccc_small_batches_in_frame_groups_and_16_bit_submit_to(rip_lib, oracle):
+    """Two corners of this round's host / latency changes.  (1) The ccc estimator's zero-hand-back of its histogram counters is
+    tracked for unsplit batches only: with the batch cut into frame groups on two streams (overlap_groups) every group clears
+    its own counters -- small ccc batches with undistortion, groups 2 and 3, against the oracle.  (2) rip_submit_to with a
+    16-bit Bayer frame (the opt-in extension): the result lands in the caller's page-locked uint16 array."""
+    import torch
+    from raw_image_pipeline_amd import RawImagePipeline
+    from raw_image_pipeline_amd.pipeline import host_alloc
+    w, h = 384, 240
+    filt, bias = synth.ccc_model()
+    pipe = RawImagePipeline(False, "", "", "", device=0)
+    pipe.set_ccc_model(filt, bias)
+    pipe.set_ccc_kalman_model(1.0, 10.0)
+    occ = oracle.CCC(filt, bias)
+    occ.set_kalman_model(1.0, 10.0)
+    c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=False, gamma=True, gamma_k=0.8, vig=True, undistort=True,
+            cam=synth.camera_model(w, h))
+    configure(pipe, c)
+    seed = 9900
+    for groups, n in ((2, 5), (3, 7), (1, 2), (2, 4), (1, 1)):
+        pipe.set_tunable("overlap_groups", groups)
+        frames = np.stack([synth.gen_frame(w, h, "bayer_bggr8", seed=seed + i, kind="scene", tint=(0.6 + 0.03 * i, 1.0, 0.55)) for i in range(n)])
+        seed += n
+        out = pipe.apply_device(torch.from_numpy(frames).cuda(), "bayer_bggr8").cpu().numpy()
+        for i in range(n):
+            ref, _ = oracle_run(oracle, c, frames[i], "bayer_bggr8", ccc=occ)
+            assert_images_equal(out[i], ref, "ccc, %d frames in %d groups, frame %d" % (n, groups, i), TOL_DECLARED)
+    # (2)
+    p16 = RawImagePipeline(False, "", "", "", device=0)
+    configure(p16, cfg())
+    p16.set_debayer_16bit(True)
+    f16 = (synth.gen_frame(w, h, "bayer_rggb8", seed=5, kind="scene").astype(np.uint16) * 257)
+    want = p16.process(f16, "bayer_rggb16")
+    dst = host_alloc((h, w, 3), np.uint16)
+    got = p16.collect(p16.submit(f16, "bayer_rggb16", out=dst))
+    assert got is dst and got.dtype == np.uint16 and np.array_equal(got, want)
