@@ -68,7 +68,8 @@ constexpr int fast_waves_per_simd() {
 }
 
 // The per-pixel stages after the demosaic for the four pixels of one row; returns the 12 interleaved output bytes.
-template <int BITS, int WB>
+// BIAS: see apply_cc_f
+template <int BITS, int WB, int BIAS = 1>
 __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb& w, const FastTabs<BITS>& tb, const CcRegs& cc,
                                             const HsvRegs& hr, const float (&mask)[4], int (&q)[4][3]) {
 #pragma unroll
@@ -80,7 +81,7 @@ __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb&
     for (int k = 0; k < 4; k++) {
       if constexpr ((BITS & ST_CC) != 0) {
         float o[3];
-        apply_cc_f(p, cc, q[k][0], q[k][1], q[k][2], o);
+        apply_cc_f<BIAS>(p, cc, q[k][0], q[k][1], q[k][2], o);
         // saturate_cast<uchar> into byte 1 of the dword: (v << 8) >> 6 = 4 v, a full-rate right shift
 #pragma unroll
         for (int c = 0; c < 3; c++) lin_off[k][c] = __builtin_amdgcn_cvt_pk_u8_f32(o[c], 1, 0u) >> 6;
@@ -98,12 +99,12 @@ __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb&
       // the colour matrix is the last stage: its results are converted straight into their place in the packed output
       float of[4][3];
 #pragma unroll
-      for (int k = 0; k < 4; k++) apply_cc_f(p, cc, q[k][0], q[k][1], q[k][2], of[k]);
+      for (int k = 0; k < 4; k++) apply_cc_f<BIAS>(p, cc, q[k][0], q[k][1], q[k][2], of[k]);
       return pack4_from_floats(of);
     }
     if constexpr ((BITS & ST_CC) != 0) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) apply_cc(p, cc, q[k][0], q[k][1], q[k][2]);
+      for (int k = 0; k < 4; k++) apply_cc<BIAS>(p, cc, q[k][0], q[k][1], q[k][2]);
     }
     if constexpr ((BITS & ST_GAMMA) != 0) {
 #pragma unroll

@@ -221,19 +221,25 @@ struct HsvRegs {
   }
 };
 // color_calibration.cpp:93-103: ((m0*B + m1*G) + m2*R) + bias in float32, no FMA
+// BIAS: 1 = test the (wave-uniform) bias per call; 0 = the caller knows it is all zero (t + 0.0f == t up to the sign of
+// zero, which the saturating conversion drops) -- the fast kernel tests once per launch and runs a body without the branch
+template <int BIAS = 1>
 __device__ __forceinline__ void apply_cc_f(const ChainParams& p, const CcRegs& cc, int b, int g, int r, float (&o)[3]) {
   float fb = (float)b, fg = (float)g, fr = (float)r;
 #pragma unroll
   for (int c = 0; c < 3; c++) o[c] = fb * cc.m[c * 3] + fg * cc.m[c * 3 + 1] + fr * cc.m[c * 3 + 2];
-  if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
-    keep_branch();
+  if constexpr (BIAS != 0) {
+    if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
+      keep_branch();
 #pragma unroll
-    for (int c = 0; c < 3; c++) o[c] = o[c] + p.cc_bias[c];
+      for (int c = 0; c < 3; c++) o[c] = o[c] + p.cc_bias[c];
+    }
   }
 }
+template <int BIAS = 1>
 __device__ __forceinline__ void apply_cc(const ChainParams& p, const CcRegs& cc, int& b, int& g, int& r) {
   float o[3];
-  apply_cc_f(p, cc, b, g, r, o);
+  apply_cc_f<BIAS>(p, cc, b, g, r, o);
   b = sat_round_u8(o[0]);
   g = sat_round_u8(o[1]);
   r = sat_round_u8(o[2]);
@@ -508,9 +514,16 @@ __device__ __forceinline__ void vignette_n(const VigTabs& tb, const float* mask,
     z[k] = mad24_cs(mul24(fz[k], fz[k]) >> 14, fz[k], -(kZoff << 14)) >> 14;
   }
   // abToXZ_b's linear segment (i <= 3390: L* below ~8) is rare: one wave-uniform test for the group
-  int lo = min(fx[0], fz[0]);
+  int lo;
+  if constexpr (N == 4) {
+    // eight values in three v_min3_i32 and one v_min_i32 (hipcc makes three v_min + two v_min3 of the linear chain)
+    const int m0 = min(min(fx[0], fz[0]), fx[1]), m1 = min(min(fz[1], fx[2]), fz[2]);
+    lo = min(min(min(fx[3], fz[3]), m0), m1);
+  } else {
+    lo = min(fx[0], fz[0]);
 #pragma unroll
-  for (int k = 1; k < N; k++) lo = min(lo, min(fx[k], fz[k]));
+    for (int k = 1; k < N; k++) lo = min(lo, min(fx[k], fz[k]));
+  }
   if (__builtin_amdgcn_ballot_w64(lo <= 3390) != 0ull) {
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -853,11 +866,19 @@ __device__ __forceinline__ void debayer_rows_any(const RowPrep& r0, const RowPre
 
 // OpenCV's border replication on a demosaiced 4x2 tile: column 0 := column 1, column W-1 := W-2,
 // then row 0 := row 1, row H-1 := H-2
-__device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int cols, Planar (&out)[2]) {
+// reversed: the planar bytes are in mirrored order (byte 3 = column x0: the 180-degree flip folded into the demosaic's byte
+// merges, debayer_tile_sel), so the two column fix-ups trade places
+// the wave-level test of debayer_fix_edges: lanes whose tile touches the image border.  It depends on the position only, so a
+// kernel that walks the frames of a batch innermost takes it once per item (hipcc re-evaluates a ballot inside the loop with a
+// v_cndmask / v_cmp pair per trip)
+__device__ __forceinline__ unsigned long long debayer_edge_lanes(int y0, int x0, int rows, int cols) {
+  return __builtin_amdgcn_ballot_w64(x0 == 0 || x0 + 4 == cols || y0 == 0 || y0 + 2 == rows);
+}
+__device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int cols, Planar (&out)[2], bool reversed, unsigned long long edge_lanes) {
   // interior items (all but a 1 / (rows / 2) + 1 / (cols / 4) fraction) skip all of it behind one wave-uniform test
-  const bool edge = x0 == 0 || x0 + 4 == cols || y0 == 0 || y0 + 2 == rows;
-  if (__builtin_amdgcn_ballot_w64(edge) == 0ull) return;
-  if (x0 == 0) {
+  if (edge_lanes == 0ull) return;
+  const bool first_col = x0 == 0, last_col = x0 + 4 == cols;
+  if (reversed ? last_col : first_col) {
 #pragma unroll
     for (int ly = 0; ly < 2; ly++) {
       out[ly].b = (out[ly].b & 0xFFFFFF00u) | ((out[ly].b >> 8) & 0xFFu);
@@ -865,7 +886,7 @@ __device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int 
       out[ly].r = (out[ly].r & 0xFFFFFF00u) | ((out[ly].r >> 8) & 0xFFu);
     }
   }
-  if (x0 + 4 == cols) {
+  if (reversed ? first_col : last_col) {
 #pragma unroll
     for (int ly = 0; ly < 2; ly++) {
       out[ly].b = (out[ly].b & 0x00FFFFFFu) | ((out[ly].b << 8) & 0xFF000000u);
@@ -875,6 +896,9 @@ __device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int 
   }
   if (y0 == 0) out[0] = out[1];
   if (y0 + 2 == rows) out[1] = out[0];
+}
+__device__ __forceinline__ void debayer_fix_edges(int y0, int x0, int rows, int cols, Planar (&out)[2], bool reversed = false) {
+  debayer_fix_edges(y0, x0, rows, cols, out, reversed, debayer_edge_lanes(y0, x0, rows, cols));
 }
 // demosaic of the 4x2 tile at (y0, x0) including OpenCV's border replication
 __device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int rx, int y0, int x0, int rows, int cols,
@@ -886,6 +910,51 @@ __device__ __forceinline__ void debayer_tile_any(const Window& win, int ry, int 
     default: debayer_swar<1, 1>(win, out); break;
   }
   debayer_fix_edges(y0, x0, rows, cols, out);
+}
+
+// The same tile with the column parity of the R samples AND the 180-degree flip folded into the selectors of the six byte
+// merges (v_perm_b32 with the selector in an SGPR): one code path for the four patterns, no byte reversal afterwards.
+// Selector of "byte lanes of parity `par` from the first operand, the others from the second", output mirrored or not:
+// output byte k takes source byte j = mirrored ? 3 - k : k; v_perm_b32 numbers the first operand's bytes 4..7, the second's 0..3.
+struct DemosaicSel {
+  uint32_t first, second;  // red-site lanes of image row y0 / of row y0 + 1 (the complementary lanes)
+  int ry;                  // 1: row y0 is the blue row -- every (b, r) pair comes out exchanged
+  int mirrored;
+};
+__device__ __forceinline__ uint32_t merge_selector(int par, int mirrored) {
+  return mirrored ? (par == 0 ? 0x04010603u : 0x00050207u) : (par == 0 ? 0x03060104u : 0x07020500u);
+}
+__device__ __forceinline__ DemosaicSel demosaic_selectors(int ry, int rx, int mirrored) {
+  const int par = (rx ^ ry) & 1;  // parity of the columns whose byte lanes take the red-row roles in image row y0
+  return DemosaicSel{merge_selector(par, mirrored), merge_selector(par ^ 1, mirrored), ry, mirrored};
+}
+__device__ __forceinline__ RowPgq debayer_row_sel(const RowPrep& up, const RowPrep& at, const RowPrep& dn, uint32_t sel) {
+  const uint32_t H = at.h;
+  const uint32_t V = __builtin_amdgcn_lerp(up.c, dn.c, 0x01010101u);
+  const uint32_t X4 = __builtin_amdgcn_lerp(H, V, ~(at.hx | (up.c ^ dn.c)));  // left, right, up, down
+  const uint32_t D4 = __builtin_amdgcn_lerp(up.h, dn.h, ~(up.hx | dn.hx));    // the four diagonal neighbours
+  const uint32_t C = at.c;
+  return RowPgq{__builtin_amdgcn_perm(D4, V, sel), __builtin_amdgcn_perm(X4, C, sel), __builtin_amdgcn_perm(C, H, sel)};
+}
+__device__ __forceinline__ void swap_regs(uint32_t& a, uint32_t& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void debayer_tile_sel(const Window& win, const DemosaicSel& ds, int y0, int x0, int rows, int cols,
+                                                 unsigned long long edge_lanes, Planar (&out)[2]) {
+  RowPrep r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) r[k] = prep_row(win.w[k][0], win.w[k][1], win.w[k][2]);
+  const RowPgq a = debayer_row_sel(r[0], r[1], r[2], ds.first);
+  const RowPgq c = debayer_row_sel(r[1], r[2], r[3], ds.second);
+  out[0].b = a.p;
+  out[0].g = a.g;
+  out[0].r = a.q;
+  out[1].b = c.q;
+  out[1].g = c.g;
+  out[1].r = c.p;
+  if (ds.ry != 0) {  // scalar branch; the exchange happens in place (no copies on either side)
+    swap_regs(out[0].b, out[0].r);
+    swap_regs(out[1].b, out[1].r);
+  }
+  debayer_fix_edges(y0, x0, rows, cols, out, ds.mirrored != 0, edge_lanes);
 }
 
 // planar -> interleaved BGR (12 bytes) with six v_perm_b32
@@ -922,6 +991,19 @@ __device__ __forceinline__ void store12(__amdgpu_buffer_rsrc_t frame, unsigned o
 __device__ __forceinline__ void store12(__amdgpu_buffer_rsrc_t frame, unsigned off, const Pack3& v, bool nt) {
   u32x3 u = {v.a, v.b, v.c};
   if (nt) {
+    keep_branch();
+    __builtin_amdgcn_raw_buffer_store_b96(u, frame, (int)off, 0, 2);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b96(u, frame, (int)off, 0, 0);
+  }
+}
+
+// the same with the flag as the kernel argument itself (an SGPR compared on the scalar unit: a bool computed outside a loop
+// comes back through v_cndmask / v_cmp pairs in every trip)
+__device__ __forceinline__ void store12(__amdgpu_buffer_rsrc_t frame, unsigned off, const Pack3& v, int nt) {
+  u32x3 u = {v.a, v.b, v.c};
+  asm volatile("" : "+s"(nt));  // keeps the comparison here, on the scalar unit (hipcc otherwise hoists it as a lane mask)
+  if (nt != 0) {
     keep_branch();
     __builtin_amdgcn_raw_buffer_store_b96(u, frame, (int)off, 0, 2);
   } else {

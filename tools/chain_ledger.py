@@ -62,12 +62,82 @@ def loop_blocks(lines):
     depth = max([int(d) for b in blocks for d in re.findall(r"Depth=(\d+)", b["comment"])] or [0])
     if depth == 0:
         return blocks
+    # round 5: the kernel holds two frame loops (fast_chunks<PLAIN = true / false>); the benchmark runs the first one in
+    # code order (no debayered tap, zero colour bias)
     hdr = None
     for b in blocks:
         if re.search(r"Loop Header: Depth=%d" % depth, b["comment"]):
             hdr = b["label"].lstrip(".L")
-    return [b for b in blocks if re.search(r"Loop Header: Depth=%d" % depth, b["comment"]) or
-            ("Header=%s Depth=%d" % (hdr, depth)) in b["comment"]]
+            break
+    return [b for b in blocks if ("Header=%s Depth=%d" % (hdr, depth)) in b["comment"] or
+            (b["label"].lstrip(".L") == hdr and re.search(r"Loop Header: Depth=%d" % depth, b["comment"]))]
+
+
+RARE_BLOCK = [re.compile(r"0x4ded21"), re.compile(r"^v_swap_b32"), re.compile(r"rip_generic_hsv_gains")]
+
+
+def is_rare(b):
+    ins = b["ins"]
+    if any(r.search(t) for t in ins for r in RARE_BLOCK):
+        return True
+    if sum(1 for t in ins if t.startswith("v_add_f32") and ic.SGPR_SRC.search(t.split(",", 1)[1])) >= 3:
+        return True  # colour bias != 0
+    if sum(1 for t in ins if t.startswith("v_perm_b32")) >= 6 and any("buffer_store_dwordx3" in t for t in ins):
+        return True  # debayered tap
+    if sum(1 for t in ins if re.match(r"v_lsh(l|r)rev_b32_e32 v\d+, 8, v\d+", t)) >= 6:
+        return True  # image-border fix-ups of the demosaic
+    if sum(1 for t in ins if t.startswith("v_cndmask_b32_e64")) >= 3 and len(ins) <= 12:
+        return True  # first / last row fix-up
+    if any(t.startswith("v_cmp_gt_i32") for t in ins) and any(t.startswith("s_and_saveexec") for t in ins) and len(ins) <= 4:
+        return True  # per-lane tests of the abToXZ linear segment
+    return False
+
+
+def executed_path(blocks):
+    """The blocks one trip of the frame loop runs in the benchmark: the cheapest walk from the loop header back to it, where
+    entering a block recognised as never-taken (is_rare) costs more than any detour (round 5; replaces the neighbourhood
+    heuristics of rounds 2-4).  Edges: fall-through unless the block ends in s_branch, plus every branch target inside the loop."""
+    import heapq
+    index = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
+    n = len(blocks)
+    succ = [[] for _ in range(n)]
+    back = [False] * n
+    for i, b in enumerate(blocks):
+        fall = True
+        for t in b["ins"]:
+            m = re.match(r"s_(cbranch_\w+|branch)\s+(\.LBB\d+_\d+)", t)
+            if not m:
+                continue
+            j = index.get(m.group(2))
+            if j == 0:
+                back[i] = True
+            elif j is not None:
+                succ[i].append(j)
+            if m.group(1) == "branch":
+                fall = False
+        if fall and i + 1 < n:
+            succ[i].append(i + 1)
+    def cost(i):
+        return (10 ** 6 if is_rare(blocks[i]) else 0) + sum(1 for t in blocks[i]["ins"] if t.startswith("v_")) + 1
+    dist, prev = {0: cost(0)}, {}
+    heap = [(dist[0], 0)]
+    best = None
+    while heap:
+        d, i = heapq.heappop(heap)
+        if d > dist.get(i, 1e18):
+            continue
+        if back[i] and (best is None or d < dist[best]):
+            best = i
+        for j in succ[i]:
+            nd = d + cost(j)
+            if nd < dist.get(j, 1e18):
+                dist[j], prev[j] = nd, i
+                heapq.heappush(heap, (nd, j))
+    path, i = [], best
+    while i is not None:
+        path.append(i)
+        i = prev.get(i)
+    return [blocks[i] for i in reversed(path)]
 
 
 def price(blocks):
@@ -108,30 +178,9 @@ def main():
         for wl, pat in VARIANTS.items():
             name, lines = ic.kernel_lines(listing, pat)
             blocks = loop_blocks(lines)
-            # regions bracketed by marker instructions (laid out contiguously by LLVM): the generic colour-enhancer gains
-            bracketed, inside = set(), False
-            for i, b in enumerate(blocks):
-                if any("rip_generic_hsv_gains" in t for t in b["ins"]):
-                    inside = True
-                if inside:
-                    bracketed.add(i)
-                if any("rip_generic_hsv_end" in t for t in b["ins"]):
-                    inside = False
-            rare = [b for i, b in enumerate(blocks) if i in bracketed or any(re.search(r"0x4ded21", t) for t in b["ins"]) or
-                    sum(1 for t in b["ins"] if t.startswith("v_add_f32") and ic.SGPR_SRC.search(t.split(",", 1)[1])) >= 3 or
-                    sum(1 for t in b["ins"] if t.startswith("v_perm_b32")) >= 6 and any("buffer_store_dwordx3" in t for t in b["ins"])]
-            # a forward branch that skips a run of blocks holding a never-taken block skips all of them (the per-lane compare /
-            # exec-mask blocks in front of the abToXZ linear segment, the flow blocks around the colour-bias adds)
-            index = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
-            rare_idx = set(i for i, b in enumerate(blocks) if any(b is r for r in rare))
-            by_content = set(rare_idx)
-            for i, b in enumerate(blocks):
-                m = re.match(r"s_cbranch_(vccz|vccnz|scc0|scc1)\s+(\.LBB\d+_\d+)", b["ins"][-1]) if b["ins"] else None
-                j = index.get(m.group(2)) if m else None
-                # short skips only: the long forward branches of the loop lead to out-of-line blocks, not around a rare one
-                if j is not None and i + 1 < j <= i + 16 and any(k in by_content for k in range(i + 1, j)):
-                    rare_idx.update(range(i + 1, j))
-            rare = [b for i, b in enumerate(blocks) if i in rare_idx]
+            taken = executed_path(blocks)
+            taken_ids = set(id(b) for b in taken)
+            rare = [b for b in blocks if id(b) not in taken_ids]
             cyc, cnt, lds = price(blocks)
             rcyc, rcnt, rlds = price(rare)
             valu = sum(v for k, v in cnt.items() if k.startswith("v_"))
