@@ -185,6 +185,8 @@ class RawImagePipeline {
   void resetWhiteBalanceTemporalConsistency() { check(rip_reset_white_balance_temporal_consistency(h_)); }
   void setGpu(bool use_gpu) { check(rip_set_gpu(h_, use_gpu)); }
   void setDebug(bool debug) { check(rip_set_debug(h_, debug)); }
+  // not in the reference: contraction model of the float stages (0: baseline x86-64 OpenCV, 1: FMA-target build), rip.h
+  void setFpContraction(int mode) { check(rip_set_fp_contraction(h_, mode)); }
 
   //-----------------------------------------------------------------------------
   // Setters (hpp:66-104)

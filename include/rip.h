@@ -200,6 +200,14 @@ rip_status rip_set_gpu(rip_pipeline* p, int use_gpu);                     /* cpp
  * A file that cannot be written does not fail the frame (cv::imwrite's result is ignored by the reference too); the paths are
  * left in rip_last_error().  rip_apply_device() never dumps. */
 rip_status rip_set_debug(rip_pipeline* p, int debug);
+/* Not in the reference: which OpenCV BUILD the float stages reproduce.  The colour matrix (color_calibration.cpp:93-103 ->
+ * cv::gemm), the pca map (white_balance.cpp:122-127 -> cv::addWeighted), the HSV inverse (color_enhancer.cpp:44 ->
+ * HSV2RGB_f) and the vignetting mask (vignetting_correction.cpp:42-43) are C expressions of the form a*b + c, which GCC and
+ * Clang contract into fused multiply-adds wherever the target has them: every aarch64 build (the reference's Jetson
+ * deployment, README.md:191-201), never the baseline x86-64 one.  mode 0 (default; environment RIP_FP_CONTRACT): every
+ * product and every sum rounded; mode 1: the fused forms (oracle/rip_oracle.c contraction model 1).  The two differ by at
+ * most 1 LSB per stage on rounding ties (PARITY.md).  Anything else: RIP_ERR_INVALID_ARGUMENT. */
+rip_status rip_set_fp_contraction(rip_pipeline* p, int mode);
 
 /* ---- setters (hpp:66-104; cpp:241-383) ---------------------------------------------------- */
 rip_status rip_set_debayer(rip_pipeline* p, int enabled);                         /* hpp:66 */

@@ -15,6 +15,9 @@ HEADERS = ["rip_kernels.hpp", "rip_device.hpp", "rip_chain_dev.hpp", "rip_remap_
 # six waves per SIMD and gains 2.3 % from the extra instruction-level parallelism inside a wave (2.311 -> 2.257 ms per 256
 # frames); the same strategy costs the memory-bound remap 3.5 % and the ccc kernels 8 %, so it is not a global flag.
 PER_SOURCE_FLAGS = {"rip_chain.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# translation units compiled a second time under the contracted floating-point model (rip_device.hpp RIP_FP_CONTRACT; object
+# <name>_fc1.o): the kernels rip_set_fp_contraction(1) selects.  -ffp-contract stays off: the fused forms are written out.
+FC1_SOURCES = ["rip_chain.hip", "rip_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
 
@@ -44,9 +47,9 @@ def build(force=False, verbose=False, out=None, extra_flags=None, tag=""):
     procs = []
     bdir = os.path.join(HERE, "build" + tag)
     os.makedirs(bdir, exist_ok=True)
-    for s in SOURCES:
-        obj = os.path.join(bdir, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + os.environ.get("RIP_EXTRA_FLAGS", "").split() + list(extra_flags or []) + PER_SOURCE_FLAGS.get(s, []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+    for s, fc in [(s, 0) for s in SOURCES] + [(s, 1) for s in FC1_SOURCES]:
+        obj = os.path.join(bdir, os.path.splitext(s)[0] + ("_fc1" if fc else "") + ".o")
+        cmd = [hipcc()] + FLAGS + os.environ.get("RIP_EXTRA_FLAGS", "").split() + list(extra_flags or []) + PER_SOURCE_FLAGS.get(s, []) + (["-DRIP_FP_CONTRACT=1"] if fc else []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -319,6 +319,7 @@ struct rip_pipeline {
   mutable std::string last_error;
   int tap_mask = RIP_TAP_DEBAYERED | RIP_TAP_COLOR | RIP_TAP_PROCESSED;
   int tap_download_mask = 0;  // rip_set_tap_download: which of the kept taps rip_submit also downloads with the result
+  int fp_contract = 0;        // rip_set_fp_contraction / RIP_FP_CONTRACT: contraction model of the float stages (0 none, 1 fused)
 
   // constants on the device
   rip::DevTables h_tabs;
@@ -611,7 +612,7 @@ void ensure_tables(rip_pipeline* p) {
 
 void ensure_vignette(rip_pipeline* p, int rows, int cols) {
   if (!p->vig_dirty && p->vig_rows == rows && p->vig_cols == cols) return;
-  rip::build_vignette_mask(rows, cols, p->m.vig_scale, p->m.vig_a2, p->m.vig_a4, p->h_vig);
+  rip::build_vignette_mask(rows, cols, p->m.vig_scale, p->m.vig_a2, p->m.vig_a4, p->h_vig, p->fp_contract);
   p->d_vig.reserve(p->h_vig.size() * sizeof(float));
   HIP_CHECK(hipMemcpyAsync(p->d_vig.ptr, p->h_vig.data(), p->h_vig.size() * sizeof(float), hipMemcpyHostToDevice, p->stream));
   HIP_CHECK(hipStreamSynchronize(p->stream));
@@ -910,6 +911,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     c.hsv_gain[2] = (float)p->m.ce_value_gain;
     c.tabs = p->d_tabs.as<rip::DevTables>();
     c.vig_image = p->d_vig_image.as<uint32_t>();
+    c.fp_contract = p->fp_contract;
     return c;
   };
   if (pl.remap) {
@@ -1329,6 +1331,7 @@ rip_status rip_create(int device, int use_gpu, const char* params_path, const ch
     if (const char* e = std::getenv("RIP_PLAN_ON_HOST")) p->plan_on_host = *e && *e != '0';
     if (const char* e = std::getenv("RIP_DEBUG_DIR")) if (*e) p->debug_dir = e;
     if (const char* e = std::getenv("RIP_CCC_MODEL")) if (*e) p->ccc_model_env = e;
+    if (const char* e = std::getenv("RIP_FP_CONTRACT")) p->fp_contract = std::atoi(e) == 1 ? 1 : 0;
     if (!p->ccc_model_env.empty()) rip::ccc_load_model_file(p->ccc, p->ccc_model_env);
     *out = p;
     return RIP_OK;
@@ -1897,6 +1900,10 @@ RIP_SETTER(rip_set_color_calibration_bias, (rip_pipeline * p, const double* v, i
 RIP_SETTER(rip_set_gamma_correction, (rip_pipeline * p, int v), p->m.gamma_enabled = v != 0; p->tabs_dirty = true)
 RIP_SETTER(rip_set_gamma_correction_method, (rip_pipeline * p, const char* s), if (!s) throw InvalidArgument("null string"); p->m.gamma_method = s)
 RIP_SETTER(rip_set_gamma_correction_k, (rip_pipeline * p, double k), p->m.gamma_k = k; p->tabs_dirty = true)
+RIP_SETTER(rip_set_fp_contraction, (rip_pipeline * p, int mode),
+           if (mode != 0 && mode != 1) throw InvalidArgument("fp contraction model must be 0 (none) or 1 (fused)");
+           if (mode != p->fp_contract) p->vig_dirty = true;  // the mask plane's k = r^2 a2 + r^4 a4 is one of the contracted expressions
+           p->fp_contract = mode)
 RIP_SETTER(rip_set_vignetting_correction, (rip_pipeline * p, int v), p->m.vig_enabled = v != 0)
 RIP_SETTER(rip_set_vignetting_correction_parameters, (rip_pipeline * p, double s, double a2, double a4),
            p->m.vig_scale = s; p->m.vig_a2 = a2; p->m.vig_a4 = a4; p->vig_dirty = true)
@@ -2096,7 +2103,7 @@ rip_status rip_get_vignetting_mask(rip_pipeline* p, int rows, int cols, float* o
   return guarded(p, [&] {
     if (rows < 1 || cols < 1 || !out || capacity_floats < (size_t)rows * cols) throw InvalidArgument("vignetting mask: bad size / buffer");
     std::vector<float> m;
-    rip::build_vignette_mask(rows, cols, p->m.vig_scale, p->m.vig_a2, p->m.vig_a4, m);
+    rip::build_vignette_mask(rows, cols, p->m.vig_scale, p->m.vig_a2, p->m.vig_a4, m, p->fp_contract);
     std::memcpy(out, m.data(), m.size() * sizeof(float));
   });
 }

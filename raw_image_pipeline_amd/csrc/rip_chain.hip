@@ -515,6 +515,7 @@ void launch_fast_wb(const ChainParams& p, const ItemMap& im, int items, dim3 gri
 
 }  // namespace
 
+#if !RIP_FP_CONTRACT
 bool color_fast_geometry(const uint8_t* src, size_t step, size_t frame_stride, int rows, int cols, int kind) {
   return (kind == SRC_BGR || kind == SRC_RGB) && cols % 4 == 0 && step % 4 == 0 && frame_stride % 4 == 0 && aligned4(src) &&
          step < (1u << 24) && rows < (1 << 23) && (unsigned long long)step * (unsigned long long)rows < (1ull << 32);
@@ -551,6 +552,8 @@ bool chain_uses_rot_path(const ChainParams& p) {
          (!p.tap || ((reinterpret_cast<uintptr_t>(p.tap) & 1u) == 0 && p.tap_frame_stride % 2 == 0));
 }
 
+#endif  // !RIP_FP_CONTRACT
+
 // gridDim.y: how many groups of frames the batch is split into (every kernel here walks the frames of its group
 // innermost).  At most 16 frames per item visit (RIP_CHAIN_FRAMES) for the VALU-bound stage sets: 2448 chunks on 2048
 // persistent workgroups would leave most of the chip idle while a fifth of them does a second chunk; four times as many,
@@ -572,6 +575,14 @@ static int frame_groups(const ChainParams& p, const Tunables& tn, int cap, int b
   return std::max(1, std::min(p.n_frames, groups));
 }
 
+#if RIP_FP_CONTRACT
+// declared by the uncontracted translation unit's twin (same definitions, one copy in the library)
+int chain_uses_fast_path(const ChainParams& p);
+bool chain_uses_color_path(const ChainParams& p);
+bool chain_uses_mono_path(const ChainParams& p);
+bool chain_uses_rot_path(const ChainParams& p);
+#define launch_chain launch_chain_fc1
+#else
 size_t vig_image_bytes() { return sizeof(VigTabs); }
 void launch_vig_image(const DevTables* tabs, uint32_t* image, hipStream_t stream) {
   hipLaunchKernelGGL(vig_image_kernel, dim3(1), dim3(512), 0, stream, tabs, image);
@@ -583,8 +594,13 @@ void launch_debayer16(const Debayer16Params& p, hipStream_t stream) {
   hipLaunchKernelGGL(debayer16_kernel, dim3(grid_blocks_for(npix, 4096), p.n_frames), dim3(kBlock), 0, stream, p);
 }
 
+#endif  // RIP_FP_CONTRACT
+
 void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream) {
   if (p.n_frames <= 0) return;
+#if !RIP_FP_CONTRACT
+  if (p.fp_contract == 1) return launch_chain_fc1(p, tn, stream);
+#endif
   if (chain_uses_rot_path(p)) {
     const int nt = (p.stage_bits & ST_VIG) ? fast_threads<ST_VIG>() : fast_threads<0>();
     const int tiles_x = (p.cols / 4 + 3) / 4, tiles_y = (p.rows / 2 + nt / 4 - 1) / (nt / 4);

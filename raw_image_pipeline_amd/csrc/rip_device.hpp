@@ -24,10 +24,25 @@
 #include <cstddef>
 #include <cstdlib>
 
+// Floating-point contraction model of the float stages (PARITY.md): 0 (default) = every product and every sum rounded --
+// OpenCV built for baseline x86-64; 1 = the fused forms GCC / Clang emit wherever the target has FMA (every aarch64 build: the
+// reference's Jetson deployment), oracle/rip_oracle.c mode 1.  The translation units that hold these stages (rip_chain.hip,
+// rip_fused.hip) are compiled once per model (build.py); rip_set_fp_contraction() picks the set of kernels at launch time.
+#ifndef RIP_FP_CONTRACT
+#define RIP_FP_CONTRACT 0
+#endif
+
 namespace rip {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr bool kFpContract = RIP_FP_CONTRACT != 0;
+// a * b + c: one fma under the contracted model, multiply then add otherwise (the build runs with -ffp-contract=off, so the
+// second form stays two instructions)
+__device__ __forceinline__ float mul_add(float a, float b, float c) {
+  if constexpr (kFpContract) return __builtin_fmaf(a, b, c);
+  return a * b + c;
+}
 
 // ------------------------------------------------------------------------------------------------
 // scalar helpers
@@ -187,8 +202,9 @@ __device__ __forceinline__ void apply_wb(int mode, const FrameWb& w, int& b, int
   } else if (mode == WB_PCA) {
     float fb = (float)b, fr = (float)r;
     float b2 = fb * fb, r2 = fr * fr;
-    float bp = b2 * w.pca[0] + fb * w.pca[1];
-    float rp = r2 * w.pca[2] + fr * w.pca[3];
+    // cv::addWeighted = v_fma(A, a, v_fma(B, b, 0)): under the contracted model only the second product is rounded on its own
+    float bp = mul_add(b2, w.pca[0], fb * w.pca[1]);
+    float rp = mul_add(r2, w.pca[2], fr * w.pca[3]);
     bp = bp > 255.f ? 255.f : bp;  // THRESH_TRUNC
     rp = rp > 255.f ? 255.f : rp;
     b = sat_round_u8(bp);
@@ -226,8 +242,10 @@ struct HsvRegs {
 template <int BIAS = 1>
 __device__ __forceinline__ void apply_cc_f(const ChainParams& p, const CcRegs& cc, int b, int g, int r, float (&o)[3]) {
   float fb = (float)b, fg = (float)g, fr = (float)r;
+  // contracted model: (a0*b0 + a1*b1) + a2*b2 -> fma(a2, b2, fma(a0, b0, a1*b1)) (leftmost multiply fused first); the bias is a
+  // separate cv::add over the whole Mat and never fuses
 #pragma unroll
-  for (int c = 0; c < 3; c++) o[c] = fb * cc.m[c * 3] + fg * cc.m[c * 3 + 1] + fr * cc.m[c * 3 + 2];
+  for (int c = 0; c < 3; c++) o[c] = mul_add(fr, cc.m[c * 3 + 2], mul_add(fb, cc.m[c * 3], fg * cc.m[c * 3 + 1]));
   if constexpr (BIAS != 0) {
     if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
       keep_branch();
@@ -248,7 +266,7 @@ __device__ __forceinline__ void apply_cc(const ChainParams& p, int& b, int& g, i
   float fb = (float)b, fg = (float)g, fr = (float)r;
   float o[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) o[c] = fb * p.cc_m[c * 3] + fg * p.cc_m[c * 3 + 1] + fr * p.cc_m[c * 3 + 2];
+  for (int c = 0; c < 3; c++) o[c] = mul_add(fr, p.cc_m[c * 3 + 2], mul_add(fb, p.cc_m[c * 3], fg * p.cc_m[c * 3 + 1]));
   // t + 0.0f == t (up to the sign of zero, which the saturating conversion drops): the usual all-zero
   // bias costs nothing; the test is wave-uniform (kernel arguments)
   if (p.cc_bias[0] != 0.f || p.cc_bias[1] != 0.f || p.cc_bias[2] != 0.f) {
@@ -653,9 +671,10 @@ __device__ __forceinline__ void apply_hsv_f(const float (&hg)[3], const Tabs& tb
   const float wb = max_sat(3.f - fh, fh - 5.f);
   const float wg = max_sat(1.f - fh, fh - 3.f);
   const float wr = min_sat(fh - 1.f, 5.f - fh);
-  const float ob = fv * (1.f - fs * wb);
-  const float og = fv * (1.f - fs * wg);
-  const float orr = fv * (1.f - fs * wr);
+  // contracted model: 1 - s * w is one fnma (w = 0 and w = 1 still give tab[0] = v and tab[1] = v (1 - s) exactly)
+  const float ob = fv * mul_add(-fs, wb, 1.f);
+  const float og = fv * mul_add(-fs, wg, 1.f);
+  const float orr = fv * mul_add(-fs, wr, 1.f);
   out[0] = ob * 255.f;
   out[1] = og * 255.f;
   out[2] = orr * 255.f;

@@ -342,8 +342,14 @@ void launch_fused_bits(const RemapTiledParams& q, const ChainParams& c, unsigned
 // p.base.src / src_step / src_frame_stride / rows / cols: the BAYER frames; c: the chain's stage parameters (wb, cc, tabs,
 // pattern).  max_rect_w / max_rect_h: the plan's largest source rectangle in pixels.  Returns false -- and launches nothing --
 // when the configuration or the geometry does not qualify; the caller then runs the chain and the remap as two kernels.
+#if RIP_FP_CONTRACT
+#define launch_remap_fused launch_remap_fused_fc1
+#endif
 bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max_rect_w, int max_rect_h, const Tunables& tn, hipStream_t stream,
                         bool dry_run) {
+#if !RIP_FP_CONTRACT
+  if (c.fp_contract == 1) return launch_remap_fused_fc1(p, c, max_rect_w, max_rect_h, tn, stream, dry_run);
+#endif
   const RemapParams& b = p.base;
   if (b.n_frames <= 0) return true;
   const bool ok = tn.remap_fused != 0 && tn.remap_ring != 0 && c.src_kind == SRC_BAYER && (c.flip_angle == 0 || c.flip_angle == 180) &&

@@ -532,7 +532,9 @@ const ColorTables& color_tables() {
 // the pixels).  k depends on (|row - rows/2|, |col - cols/2|) only, so one quadrant is evaluated and mirrored --
 // the per-pixel operands are identical, only the number of pow() calls drops.  Once per (geometry, parameters);
 // the reference rebuilds it on every non-square frame (quirk Q6).
-void build_vignette_mask(int rows, int cols, double scale, double a2, double a4, std::vector<float>& mask) {
+// fp_contract = 1: the reference's own translation unit compiled for an FMA target (aarch64): pow(., 2) is a multiply and both
+// sums of products contract -- r = sqrt(fma(dx, dx, dy * dy)), k = fma(r^2, a2, r^4 * a4) (oracle/rip_oracle.c mode 1).
+void build_vignette_mask(int rows, int cols, double scale, double a2, double a4, std::vector<float>& mask, int fp_contract) {
   mask.resize((size_t)rows * cols);
   const double cy = rows / 2.0, cx = cols / 2.0;
   // distinct |2 * d| values per axis: index = |2 * i - n|
@@ -546,8 +548,12 @@ void build_vignette_mask(int rows, int cols, double scale, double a2, double a4,
       const size_t qi = (size_t)ay * (cols + 1) + ax;
       if (!have[qi]) {
         const double dy = std::fabs(row - cy), dx = std::fabs(col - cx);
-        const double r = std::sqrt(std::pow(dx, 2) + std::pow(dy, 2));
-        const double k = std::pow(r, 2) * a2 + std::pow(r, 4) * a4;
+        double r = std::sqrt(std::pow(dx, 2) + std::pow(dy, 2));
+        double k = std::pow(r, 2) * a2 + std::pow(r, 4) * a4;
+        if (fp_contract) {
+          r = std::sqrt(std::fma(dx, dx, dy * dy));
+          k = std::fma(std::pow(r, 2), a2, std::pow(r, 4) * a4);
+        }
         quad[qi] = (float)k;
         have[qi] = 1;
       }

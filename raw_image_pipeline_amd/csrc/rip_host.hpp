@@ -114,7 +114,7 @@ const ColorTables& color_tables();  // built once
 
 // vignetting_correction.cpp:32-63: the float mask plane (rows x cols, tightly packed), evaluated with the
 // reference's operation order (sqrt, pow(r, 2), pow(r, 4) in double); uploaded once per geometry / parameter set
-void build_vignette_mask(int rows, int cols, double scale, double a2, double a4, std::vector<float>& mask);
+void build_vignette_mask(int rows, int cols, double scale, double a2, double a4, std::vector<float>& mask, int fp_contract = 0);
 
 // ---------------------------------------------------------------------------------------------
 // Debug stage dumps (raw_image_pipeline.hpp:179-186 saveDebugImage): cv::normalize(NORM_MINMAX, 0..255) over all

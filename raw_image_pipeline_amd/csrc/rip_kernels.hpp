@@ -102,6 +102,8 @@ struct ChainParams {
   // the LDS tables of the vignetting variants as one ready-made image (launch_vig_image): a workgroup copies it with 16-byte
   // loads instead of rebuilding 54 KB of tables from DevTables; null: build them in the kernel
   const uint32_t* vig_image;
+  // floating-point contraction model of the float stages (rip_device.hpp RIP_FP_CONTRACT): 0 = none, 1 = fused as on FMA targets
+  int fp_contract;
 };
 
 // 16-bit Bayer extension (the reference lists bayer_*16 and rejects them, debayer.hpp:73-80 / debayer.cpp:76-78):
@@ -246,6 +248,11 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
 bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max_rect_w, int max_rect_h, const Tunables& tn, hipStream_t stream,
                         bool dry_run);
 void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream);
+// the same launchers compiled under the contracted model (the translation units built with -DRIP_FP_CONTRACT=1);
+// launch_chain / launch_remap_fused hand over to them when ChainParams::fp_contract == 1
+void launch_chain_fc1(const ChainParams& p, const Tunables& tn, hipStream_t stream);
+bool launch_remap_fused_fc1(const RemapTiledParams& p, const ChainParams& c, int max_rect_w, int max_rect_h, const Tunables& tn, hipStream_t stream,
+                            bool dry_run);
 void launch_debayer16(const Debayer16Params& p, hipStream_t stream);
 // builds the image ChainParams::vig_image points to (vig_image_bytes() bytes) from the handle's tables
 size_t vig_image_bytes();

@@ -437,6 +437,12 @@ class RawImagePipeline:
         (raw_image_pipeline.hpp:143-186)."""
         self._call("rip_set_debug", int(bool(debug)))
 
+    def set_fp_contraction(self, mode):
+        """Not in the reference: the floating-point contraction model of the float stages -- 0 (default) every product and
+        sum rounded (OpenCV built for baseline x86-64), 1 the fused forms of an FMA-target build (aarch64 / Jetson).
+        include/rip.h rip_set_fp_contraction."""
+        self._call("rip_set_fp_contraction", int(mode))
+
     DEBUG_DUMP_NAMES = ("00_debayer", "01_flip", "02_white_balancing", "03_color_calibration", "04_gamma_correction",
                         "05_vignetting_correction", "06_color_enhancer", "07_undistortion")
 
