@@ -1,6 +1,7 @@
 // rip_chain.hip -- the fused per-pixel chain (debayer -> flip -> white-balance gains -> 3x3 -> gamma -> vignetting -> HSV):
 // ONE kernel, 1 B/px read, 3 B/px written, tables in LDS, no intermediate image between the stages.
 // Shared device code and the stage-by-stage reference citations: rip_device.hpp.
+#define RIP_GAMMA_FOLD 1
 #include "rip_device.hpp"
 #include "rip_chain_dev.hpp"
 

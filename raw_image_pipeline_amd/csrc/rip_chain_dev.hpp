@@ -14,8 +14,14 @@ struct OptTab {
 };
 template <typename T>
 struct OptTab<false, T> {};
-struct GammaTab {
+// 256-byte aligned in LDS: v_cvt_pk_u8_f32 writes its byte into byte 0 of a dword that already holds the table's address, so the
+// conversion that ends the colour matrix is also the address of the look-up (pointwise4)
+#ifndef RIP_GAMMA_FOLD
+#define RIP_GAMMA_FOLD 0  // rip_chain.hip sets it; inside the remap's tiles (rip_fused.hip) the plain look-ups stay
+#endif
+struct alignas(RIP_GAMMA_FOLD ? 256 : 4) GammaTab {
   uint8_t lut[256];
+  __device__ __forceinline__ unsigned lds_address() const { return (unsigned)reinterpret_cast<uintptr_t>(&lut[0]); }
 };
 struct HsvTab {
   int32_t sdiv[256], hdiv[256];
@@ -101,6 +107,21 @@ __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb&
 #pragma unroll
       for (int k = 0; k < 4; k++) apply_cc_f<BIAS>(p, cc, q[k][0], q[k][1], q[k][2], of[k]);
       return pack4_from_floats(of);
+    }
+    if constexpr (RIP_GAMMA_FOLD != 0 && (BITS & ST_CC) != 0 && (BITS & ST_GAMMA) != 0 && (BITS & ST_HSV) == 0) {
+      // colour matrix -> gamma table -> output (the reference's default stage set): saturate_cast<uchar> lands in byte 0 of the
+      // table's LDS address, the twelve look-ups are merged like the Lab round trip's (ds_read_u8 / ds_read_u8_d16_hi pairs:
+      // two ORs and one v_lshl_or_b32 per output dword instead of two shifts, a shift-or and a three-way or)
+      const unsigned base = tb.gam.v.lds_address();
+      unsigned addr[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float o[3];
+        apply_cc_f<BIAS>(p, cc, q[k][0], q[k][1], q[k][2], o);
+#pragma unroll
+        for (int c = 0; c < 3; c++) addr[k][c] = __builtin_amdgcn_cvt_pk_u8_f32(o[c], 0, base);
+      }
+      return invg_pack4(addr);
     }
     if constexpr ((BITS & ST_CC) != 0) {
 #pragma unroll

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_cycles as ic  # noqa: E402
 
 # workload -> kernel variant substring (BITS, WB, threads): bench.py's configurations
-VARIANTS = {"config2": "chain_fast_kernelILi7ELi1ELi512E", "chain": "chain_fast_kernelILi7ELi0ELi512E",
+VARIANTS = {"config2": "chain_fast_kernelILi7ELi1ELi512E", "chain": "chain_fast_kernelILi7ELi0ELi512E", "default_chain": "chain_fast_kernelILi3ELi1ELi256E",
             "config3": "chain_fast_kernelILi8ELi2ELi256E", "config5": "chain_fast_kernelILi0ELi0ELi256E"}
 # blocks the benchmark never executes, recognised by an instruction only they contain
 RARE_MARKERS = [("abToXZ linear segment", re.compile(r"0x4ded21")), ("colour bias != 0", None), ("debayered tap", None),
@@ -73,7 +73,7 @@ def loop_blocks(lines):
             (b["label"].lstrip(".L") == hdr and re.search(r"Loop Header: Depth=%d" % depth, b["comment"]))]
 
 
-RARE_BLOCK = [re.compile(r"0x4ded21"), re.compile(r"^v_swap_b32"), re.compile(r"rip_generic_hsv_gains")]
+RARE_BLOCK = [re.compile(r"0x4ded21"), re.compile(r"^v_swap_b32")]
 
 
 def is_rare(b):
@@ -94,10 +94,12 @@ def is_rare(b):
 
 
 def executed_path(blocks):
-    """The blocks one trip of the frame loop runs in the benchmark: the cheapest walk from the loop header back to it, where
-    entering a block recognised as never-taken (is_rare) costs more than any detour (round 5; replaces the neighbourhood
-    heuristics of rounds 2-4).  Edges: fall-through unless the block ends in s_branch, plus every branch target inside the loop."""
-    import heapq
+    """The blocks one trip of the frame loop runs in the benchmark: the walk from the loop header back to it that avoids the
+    blocks recognised as never-taken (is_rare; the generic colour-enhancer gains between their marker instructions) and
+    otherwise takes the LONGER side of every branch -- in the benchmark's configuration every optional block that is not one
+    of the rare ones does run, and the structurizer's complementary `if (a) .. if (!a) ..` pairs would otherwise let a
+    shortest walk skip both sides (round 5; replaces the neighbourhood heuristics of rounds 2-4).  Edges: fall-through unless
+    the block ends in s_branch, plus every forward branch target inside the loop; the loop body is a DAG."""
     index = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
     n = len(blocks)
     succ = [[] for _ in range(n)]
@@ -111,33 +113,36 @@ def executed_path(blocks):
             j = index.get(m.group(2))
             if j == 0:
                 back[i] = True
-            elif j is not None:
+            elif j is not None and j > i:
                 succ[i].append(j)
             if m.group(1) == "branch":
                 fall = False
         if fall and i + 1 < n:
             succ[i].append(i + 1)
-    def cost(i):
-        return (10 ** 6 if is_rare(blocks[i]) else 0) + sum(1 for t in blocks[i]["ins"] if t.startswith("v_")) + 1
-    dist, prev = {0: cost(0)}, {}
-    heap = [(dist[0], 0)]
-    best = None
-    while heap:
-        d, i = heapq.heappop(heap)
-        if d > dist.get(i, 1e18):
-            continue
-        if back[i] and (best is None or d < dist[best]):
-            best = i
+    rare = [is_rare(b) for b in blocks]
+    inside = False
+    for i, b in enumerate(blocks):  # the generic colour-enhancer gains: everything after the block that opens the bracket
+        if inside:
+            rare[i] = True
+        if any("rip_generic_hsv_gains" in t for t in b["ins"]):
+            inside, rare[i] = True, False
+        if any("rip_generic_hsv_end" in t for t in b["ins"]):
+            inside = False
+    score = [None] * n
+    nxt = [None] * n
+    for i in range(n - 1, -1, -1):
+        own = (-10 ** 6 if rare[i] else 0) + sum(1 for t in blocks[i]["ins"] if t.startswith("v_"))
+        best, arg = (0, None) if back[i] else (None, None)
         for j in succ[i]:
-            nd = d + cost(j)
-            if nd < dist.get(j, 1e18):
-                dist[j], prev[j] = nd, i
-                heapq.heappush(heap, (nd, j))
-    path, i = [], best
+            if score[j] is not None and (best is None or score[j] > best):
+                best, arg = score[j], j
+        if best is not None:
+            score[i], nxt[i] = own + best, arg
+    path, i = [], 0
     while i is not None:
         path.append(i)
-        i = prev.get(i)
-    return [blocks[i] for i in reversed(path)]
+        i = nxt[i]
+    return [blocks[i] for i in path]
 
 
 def price(blocks):
