@@ -69,7 +69,8 @@ void rip_destroy(rip_pipeline* p);
 const char* rip_last_error(const rip_pipeline* p);
 /* HIP stream (hipStream_t) all device work of this handle is enqueued on; default: the
  * null stream.  The caller keeps ownership.  A switch orders the new stream behind the work this handle left on the old
- * one (its scratch state crosses frame calls in stream order). */
+ * one (its scratch state crosses frame calls in stream order): an event is recorded on the OLD stream during this call, so the
+ * stream passed to the previous rip_set_stream must still exist when the next one is made -- destroy it only afterwards. */
 rip_status rip_set_stream(rip_pipeline* p, void* hip_stream);
 
 /* ---- frame API ----------------------------------------------------------------------- */
@@ -157,7 +158,9 @@ rip_status rip_get_image(rip_pipeline* p, int which, uint8_t* out, size_t out_ca
 /* The same image without a copy, for frames that came through rip_collect: the final image always, the taps named by
  * rip_set_tap_download are downloaded together with the result, so after rip_collect *view points into the handle's pinned host memory (valid as long as the
  * rip_collect view: until the next rip_collect on the handle or until a rip_submit takes the slot).  *view is NULL -- with
- * the geometry still reported -- when the image only exists on the device (frames of rip_apply): use rip_get_image then.
+ * the geometry still reported -- when the image only exists on the device (frames of rip_apply; images whose download went
+ * into a buffer the caller named with rip_submit_to: that buffer is the caller's again once the ticket is collected and the
+ * library does not look at it any more): use rip_get_image then.
  * hpp:134-137 (getDistDebayeredImage / getDistColorImage / getProcessedImage return Mat headers, no copy either). */
 rip_status rip_get_image_view(rip_pipeline* p, int which, const uint8_t** view, int* rows, int* cols, int* channels);
 /* Which of the kept taps (RIP_TAP_DEBAYERED | RIP_TAP_COLOR) rip_submit ALSO downloads into pinned host memory together

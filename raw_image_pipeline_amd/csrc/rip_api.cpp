@@ -204,7 +204,9 @@ class CopyPool {
 // waits for the oldest frame in flight on the device to finish before it enqueues a fourth one -- work that has to finish
 // before the new frame's download can start anyway.  RIP_RING_INFLIGHT changes the limit (0 = none).
 struct InflightGate {
-  std::mutex mu;
+  // One mutex and one queue per device: a submit that waits at the limit on device 0 holds device 0's lock only;
+  // submits and collects of handles on the other devices of a multi-GPU rig go on.
+  std::mutex mu[64];
   std::deque<hipEvent_t> q[64];  // per device: ev_done of the frames enqueued and not yet known to be complete, oldest first
   int cap() {
     static const int c = [] {
@@ -216,11 +218,11 @@ struct InflightGate {
   void admit(int device) {
     const int c = cap();
     if (c <= 0) return;
-    // The wait happens under the lock on purpose: an event in the queue belongs to some handle's slot, and forget() --
+    // The wait happens under the DEVICE's lock on purpose: an event in the queue belongs to some handle's slot, and forget() --
     // called before a slot's events are destroyed or recorded again -- must not get past it while it is waited on.  The wait
-    // is for a frame that is already enqueued in full (at most one frame time), and whoever else wants the lock meanwhile is
-    // either about to wait for the same frame (another submit at the limit) or finishes a collect a moment later.
-    std::lock_guard<std::mutex> lk(mu);
+    // is for a frame that is already enqueued in full (at most one frame time), and whoever else wants this device's lock
+    // meanwhile is either about to wait for the same frame (another submit at the limit) or finishes a collect a moment later.
+    std::lock_guard<std::mutex> lk(mu[device & 63]);
     auto& d = q[device & 63];
     while ((int)d.size() >= c) {
       hipEvent_t e = d.front();
@@ -230,14 +232,15 @@ struct InflightGate {
   }
   void enqueued(int device, hipEvent_t e) {
     if (cap() <= 0) return;
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<std::mutex> lk(mu[device & 63]);
     q[device & 63].push_back(e);
   }
-  void forget(hipEvent_t e) {  // the frame is complete, or its event is about to be destroyed / recorded again
-    if (!e) return;
-    std::lock_guard<std::mutex> lk(mu);
-    for (auto& d : q)
-      for (auto it = d.begin(); it != d.end();) it = (*it == e) ? d.erase(it) : it + 1;
+  // the frame is complete, or its event is about to be destroyed / recorded again.  device: where it was enqueued (< 0: never)
+  void forget(int device, hipEvent_t e) {
+    if (!e || device < 0) return;
+    std::lock_guard<std::mutex> lk(mu[device & 63]);
+    auto& d = q[device & 63];
+    for (auto it = d.begin(); it != d.end();) it = (*it == e) ? d.erase(it) : it + 1;
   }
 };
 InflightGate& inflight_gate() {
@@ -257,6 +260,7 @@ struct RingSlot {
   // where this frame's downloads go: the slot's own pinned buffers above, or the page-locked buffers the caller gave rip_submit_to
   void* dst_out = nullptr;
   void* dst_tap[2] = {nullptr, nullptr};
+  int gate_device = -1;  // device whose InflightGate queue holds ev_done (set when the frame is enqueued)
   size_t h_tap_cap[2] = {0, 0};
   hipEvent_t ev_up = nullptr, ev_kernels = nullptr, ev_done = nullptr;
   hipEvent_t ev_start = nullptr, ev_dl_start = nullptr;  // RIP_DEBUG_RING only: before the upload / the download (the other three then carry timestamps too)
@@ -295,7 +299,8 @@ struct RingSlot {
       h_tap[i] = nullptr;
       h_tap_cap[i] = 0;
     }
-    inflight_gate().forget(ev_done);
+    inflight_gate().forget(gate_device, ev_done);
+    gate_device = -1;
     for (hipEvent_t* e : {&ev_up, &ev_kernels, &ev_done, &ev_start, &ev_dl_start}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
@@ -1585,7 +1590,7 @@ rip_status submit_impl(rip_pipeline* p, const uint8_t* image, int rows, int cols
     // caller's buffer is free again when this call returns whatever the runtime does with an asynchronous 2-D copy from
     // pageable memory (above its staging threshold it pins the pages in place and copies after the call has returned).
     const size_t row_bytes = (size_t)cols * channels * eb;
-    inflight_gate().forget(sl.ev_done);  // the slot's previous frame (collected, or it would not have been picked)
+    inflight_gate().forget(sl.gate_device, sl.ev_done);  // the slot's previous frame (collected, or it would not have been picked)
     inflight_gate().admit(p->device);
     if (sl.ev_start) HIP_CHECK(hipEventRecord(sl.ev_start, p->ul_stream));
     if (host_pointer_is_pinned(image)) {
@@ -1616,6 +1621,7 @@ rip_status submit_impl(rip_pipeline* p, const uint8_t* image, int rows, int cols
     if (sl.dl_col) HIP_CHECK(hipMemcpyAsync(sl.dst_tap[1], sl.d_tap_col.ptr, mid_bytes, hipMemcpyDeviceToHost, p->dl_stream));
     HIP_CHECK(hipEventRecord(sl.ev_done, p->dl_stream));
     inflight_gate().enqueued(p->device, sl.ev_done);
+    sl.gate_device = p->device;
     sl.pl = pl;
     sl.ticket = p->next_ticket++;
     sl.busy = true;
@@ -1646,7 +1652,7 @@ rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t ou
     if (out && out_capacity < out_bytes) throw CapacityError("output buffer too small: need " + std::to_string(out_bytes) + " bytes");
     DeviceGuard device_guard(p->device);
     HIP_CHECK(hipEventSynchronize(sl->ev_done));
-    inflight_gate().forget(sl->ev_done);
+    inflight_gate().forget(sl->gate_device, sl->ev_done);
     if (sl->ev_start) {
       float up = 0, kern = 0, down = 0, all = 0, copy = 0;
       (void)hipEventElapsedTime(&copy, sl->ev_dl_start, sl->ev_done);
@@ -1674,9 +1680,12 @@ rip_status rip_collect(rip_pipeline* p, uint64_t ticket, uint8_t* out, size_t ou
       p->last_cols[which] = c;
       p->last_cn[which] = pl.channels;
     };
-    remember(RIP_IMAGE_DEBAYERED, &sl->d_tap_deb, sl->dl_deb ? sl->dst_tap[0] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_deb);
-    remember(RIP_IMAGE_COLOR, &sl->d_tap_col, sl->dl_col ? sl->dst_tap[1] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_col);
-    remember(RIP_IMAGE_PROCESSED, &sl->d_out, sl->dst_out, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0 && eb1);
+    // The getters may read a host copy only where it is the HANDLE's pinned buffer.  Destinations the caller named
+    // (rip_submit_to) are the caller's again from this point on -- rip.h only asks for them until the ticket is collected:
+    // they may be freed or edited, so the getters go back to the device image in the slot this frame keeps held.
+    remember(RIP_IMAGE_DEBAYERED, &sl->d_tap_deb, sl->dl_deb && sl->dst_tap[0] == sl->h_tap[0] ? sl->dst_tap[0] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_deb);
+    remember(RIP_IMAGE_COLOR, &sl->d_tap_col, sl->dl_col && sl->dst_tap[1] == sl->h_tap[1] ? sl->dst_tap[1] : nullptr, pl.mid_rows, pl.mid_cols, sl->has_col);
+    remember(RIP_IMAGE_PROCESSED, &sl->d_out, sl->dst_out == sl->h_out ? sl->dst_out : nullptr, pl.out_rows, pl.out_cols, (p->tap_mask & RIP_TAP_PROCESSED) != 0 && eb1);
     if (out_rows) *out_rows = pl.out_rows;
     if (out_cols) *out_cols = pl.out_cols;
     if (out_channels) *out_channels = pl.channels;

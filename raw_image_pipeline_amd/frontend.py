@@ -303,7 +303,21 @@ class CameraRig:
         if mode == "sequential" or len(jobs) < 2:
             return [run(j) for j in jobs]
         if mode == "pipelined":
-            sent = [cam.submit(img, enc, stamp=stamp, frame_id="cam%d" % c) for c, (cam, img, enc) in jobs]
+            sent = []
+            try:
+                for c, (cam, img, enc) in jobs:
+                    sent.append(cam.submit(img, enc, stamp=stamp, frame_id="cam%d" % c))
+            except BaseException:
+                # camera k refused its frame (bad encoding, ring full): cameras 0 .. k-1 already have this trigger's frame in
+                # flight.  Collect them before the error leaves -- left in flight they would come back on the NEXT trigger and
+                # those cameras would publish the previous trigger's images from then on (camera_rig.hpp does the same)
+                for ok, (c, (cam, img, enc)) in zip(sent, jobs):
+                    if ok:
+                        try:
+                            cam.collect(copy=False)
+                        except Exception:  # noqa: BLE001 -- the first error is the one to report
+                            pass
+                raise
             return [cam.collect(copy=copy) if ok else [] for ok, (c, (cam, img, enc)) in zip(sent, jobs)]
         if mode != "threaded":
             raise ValueError("mode must be 'pipelined', 'threaded' or 'sequential'")

@@ -68,6 +68,16 @@ def _as_doubles(values, n=None):
     return arr, len(values)
 
 
+def _wrap_pinned(raw, shape, dtype):
+    """THE array over a ctypes byte buffer: built in one step, so that its ``base`` is the buffer object and not another
+    ndarray.  numpy collapses the base chain of a view through every non-owning ndarray until it meets something that is not
+    one: a slice / reshape / reversed view of this array therefore references THIS array -- the object the ``OutputPool``
+    counts references of.  (Until round 5 this was ``np.frombuffer(raw).reshape(shape)``: views of the reshaped array
+    referenced the hidden frombuffer array, the pool saw no reference and recycled page-locked memory a caller's slice still
+    looked at -- ADVICE round 4.)"""
+    return np.ndarray(tuple(shape), dtype=np.dtype(dtype), buffer=raw)
+
+
 def host_alloc(shape, dtype=np.uint8):
     """A numpy array over page-locked host memory (rip_host_alloc): frames handed to ``submit`` from it are uploaded
     asynchronously without the staging copy a pageable frame gets -- and must stay untouched until their ``collect``.
@@ -84,7 +94,7 @@ def host_alloc(shape, dtype=np.uint8):
         raise MemoryError("rip_host_alloc(%d) failed" % n)
     raw = (C.c_uint8 * max(n, 1)).from_address(ptr)
     weakref.finalize(raw, lib.rip_host_free, C.c_void_p(ptr))  # the ctypes object is the base of every view below
-    return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    return _wrap_pinned(raw, shape, dtype)
 
 
 class OutputPool:

@@ -182,3 +182,26 @@ def test_camera_rig_overlaps_cameras_with_identical_results(rip_lib, capsys, tmp
             break
         ratio = max(ratio, max(timed(*fast) for _ in range(2)) / max(timed("sequential", True) for _ in range(2)))
     assert ratio >= bar, (ratio, rates)
+
+
+@pytest.mark.gpu
+def test_camera_rig_trigger_that_fails_half_way_leaves_no_frame_in_flight(rip_lib):
+    """camera 2 of a pipelined trigger refuses its frame (an encoding the reference throws on,
+    debayer.cpp:76-78).  Cameras 0 and 1 had already submitted: their frames must be drained before the error leaves, or they
+    come back on the NEXT trigger and those cameras publish the previous trigger's images from then on."""
+    from raw_image_pipeline_amd.frontend import CameraRig
+    w, h, ncam = 128, 96, 4
+    rig = CameraRig([{"output_prefix": "/cam%d" % c, "gamma_correction/enabled": True, "gamma_correction/k": 0.8} for c in range(ncam)], n_devices=1)
+    first = [synth.gen_frame(w, h, "bayer_rggb8", seed=10 + c, kind="scene") for c in range(ncam)]
+    second = [synth.gen_frame(w, h, "bayer_rggb8", seed=20 + c, kind="scene") for c in range(ncam)]
+    with pytest.raises(ValueError):
+        rig.on_images(first, ["bayer_rggb8", "bayer_rggb8", "bayer_rggb16", "bayer_rggb8"], stamp=1.0, mode="pipelined")
+    assert all(not getattr(cam, "_inflight", []) for cam in rig.streams)
+    got = rig.on_images(second, ["bayer_rggb8"] * ncam, stamp=2.0, mode="pipelined")
+    ref = rig.on_images(second, ["bayer_rggb8"] * ncam, stamp=2.0, mode="sequential")
+    for c in range(ncam):
+        a = {m["topic"]: m for m in got[c]}
+        b = {m["topic"]: m for m in ref[c]}
+        assert a.keys() == b.keys()
+        for t in a:
+            assert a[t]["stamp"] == 2.0 and np.array_equal(a[t]["image"], b[t]["image"]), (c, t)

@@ -326,3 +326,31 @@ def test_output_pool_recycles_only_arrays_nobody_references():
     many = [pool.take((4, 5, 3)) for _ in range(6)]   # more than the limit in use at once: plain allocations, never shared
     assert len({id(m) for m in many}) == 6
     assert len(pool._arrays[((4, 5, 3), np.dtype(np.uint8).str)]) <= 3
+
+
+def test_pinned_output_pool_counts_views_too(monkeypatch):
+    """a page-locked pool array does not own its memory, and numpy collapses the base of a view of a
+    plain non-owning array onto the hidden buffer object -- the pool then saw no reference and recycled memory a caller's
+    slice still looked at (and rip_submit_to would DMA the next frame into it).  host_alloc now builds its array directly on the
+    buffer object: views of it reference it.  rip_host_alloc is replaced by ordinary memory here (no GPU); the wrapping code is the product's."""
+    import ctypes
+    from raw_image_pipeline_amd import OutputPool, pipeline
+    monkeypatch.setattr(pipeline, "host_alloc",
+                        lambda shape, dtype=np.uint8: pipeline._wrap_pinned((ctypes.c_uint8 * (int(np.prod(shape)) * np.dtype(dtype).itemsize))(), shape, dtype))
+    pool = OutputPool(limit=4, pinned=True)
+    for make_view in (lambda a: a[1:3], lambda a: a.reshape(-1), lambda a: a[..., ::-1], lambda a: np.asarray(a)[0], lambda a: a.view(np.ndarray)):
+        a = pool.take((4, 5, 3))
+        assert not a.flags.owndata and not isinstance(a.base, np.ndarray)
+        a[...] = 7
+        view = make_view(a)
+        del a
+        b = pool.take((4, 5, 3))
+        assert not np.shares_memory(b, view), "the pool recycled an array whose view is still alive"
+        b[...] = 9
+        assert (view == 7).all()
+        del view, b
+    # once nothing references them the same arrays come back (no growth)
+    n = len(pool._arrays[((4, 5, 3), np.dtype(np.uint8).str)])
+    c = pool.take((4, 5, 3))
+    assert len(pool._arrays[((4, 5, 3), np.dtype(np.uint8).str)]) == n
+    del c
