@@ -290,6 +290,10 @@ rip_status rip_get_undistortion_maps(rip_pipeline* p, float* map_x, float* map_y
 /* Per-frame white-balance results of the most recent device batch (D2H, synchronises):
  * for frame f, out[f*8 ..] = {gain_b, gain_g, gain_r, q8_b, q8_g, q8_r, uv_x, uv_y}. */
 rip_status rip_get_white_balance_info(rip_pipeline* p, float* out, int n_frames);
+/* The ccc estimator's track over the most recent device batch (D2H, synchronises): for frame f,
+ * out[f*4 ..] = {raw_x, raw_y, x, y} -- the argmax of the response (convolutional_color_constancy.cpp:283-299) and the
+ * position after the temporal filter that the gains were taken at (:300-340); equal without temporal consistency. */
+rip_status rip_get_ccc_track(rip_pipeline* p, int* out, int n_frames);
 /* Per-kernel-class timing with HIP events recorded on the handle's stream around each launch
  * (what bench.py's roofline leg reads).  rip_profile_begin arms up to max_records event pairs;
  * rip_profile_end synchronises the stream and returns, per class, the summed elapsed

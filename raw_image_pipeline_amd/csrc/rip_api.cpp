@@ -2026,6 +2026,25 @@ rip_status rip_get_white_balance_info(rip_pipeline* p, float* out, int n_frames)
   });
 }
 
+rip_status rip_get_ccc_track(rip_pipeline* p, int* out, int n_frames) {
+  return guarded(p, [&] {
+    need(p);
+    if (!out || n_frames <= 0) throw InvalidArgument("bad arguments");
+    if (n_frames > p->last_batch_frames || !p->d_wb.ptr) throw InvalidArgument("no white-balance results for that many frames");
+    need_device(p);
+    DeviceGuard device_guard(p->device);
+    std::vector<rip::FrameWb> h(n_frames);
+    HIP_CHECK(hipMemcpyAsync(h.data(), p->d_wb.ptr, sizeof(rip::FrameWb) * n_frames, hipMemcpyDeviceToHost, p->stream));
+    HIP_CHECK(hipStreamSynchronize(p->stream));
+    for (int f = 0; f < n_frames; f++) {
+      out[4 * f + 0] = h[f].uv_raw[0];
+      out[4 * f + 1] = h[f].uv_raw[1];
+      out[4 * f + 2] = h[f].uv[0];
+      out[4 * f + 3] = h[f].uv[1];
+    }
+  });
+}
+
 rip_status rip_profile_begin(rip_pipeline* p, int max_records) {
   return guarded(p, [&] {
     need_device(p);

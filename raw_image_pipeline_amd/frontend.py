@@ -274,8 +274,11 @@ class CameraRig:
         self.devices = []
         self.hip_streams = []
         self._pool = None
+        from .sharding import streams_of_rank
+        # camera c is owned by device c mod n_devices -- the same rule a multi-process job applies per rank (sharding.py)
+        owner = {c: d for d in range(n_devices) for c in streams_of_rank(len(camera_params), n_devices, d)}
         for c, params in enumerate(camera_params):
-            dev = c % n_devices
+            dev = owner[c]
             with torch.cuda.device(dev):
                 s = torch.cuda.Stream(device=dev)
             cam = CameraStream(params, device=dev, ccc_model=ccc_model)

@@ -669,6 +669,12 @@ class RawImagePipeline:
         self._call("rip_get_white_balance_info", buf.ctypes.data_as(C.c_void_p), int(n_frames))
         return buf
 
+    def get_ccc_track(self, n_frames=1):
+        """(n, 4) int32: raw argmax (x, y) and filtered (x, y) of the ccc estimator for the frames of the last batch."""
+        buf = np.empty((n_frames, 4), np.int32)
+        self._call("rip_get_ccc_track", buf.ctypes.data_as(C.c_void_p), int(n_frames))
+        return buf
+
     def debug_plan_info(self, src_rows, src_cols):
         """Test hook (rip_debug_plan_info): dict describing the compiled remap plan of the current calibration."""
         info = (C.c_int * 9)()

@@ -128,6 +128,26 @@ def test_bench_two_rank_rehearsal_prints_one_json_line():
     assert j["config"]["frames_per_step_per_gpu"] == 8
     assert abs(j["value"] - 2 * 8 * 2 / (j["ms_per_step"] * 2 * 1e-3)) / j["value"] < 1e-3  # whole-job frames / max-over-ranks time
     assert j["scatter"]["ranks"] == 2 and j["scatter"]["frames_per_destination"] > 0 and j["scatter"]["GBps_per_destination"] > 0
+    # the end-to-end leg: rank 0's batch scattered, every rank processed what it RECEIVED, checksums equal rank 0's own
+    e = j["scatter"]["end_to_end"]
+    assert e["frames_total"] == 8 and e["frames_per_rank"] == [4, 4] and e["frames_checked_against_rank0"] == 8
+    assert e["results_equal"] is True and e["mismatched_frames"] == [] and e["constants_equal_across_ranks"] is True
+    assert e["frames_per_s_end_to_end"] > 0
+
+
+def test_bench_config5_end_to_end_leg_with_a_batch_total(rip_lib):
+    """BASELINE configs[4] through the N > 1 path (gloo rehearsal, two ranks on one device): `--workload config5 --batch-total 12`
+    -- rank 0 owns 12 frames of 3840x2160, each rank receives 6, processes them with the chain inside the remap's tiles and
+    reports checksums that must equal rank 0 processing the same ranges."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(RIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "config5", "--steps", "1", "--warmup", "1", "--batch", "4",
+           "--batch-total", "12", "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    e = j["scatter"]["end_to_end"]
+    assert e["frames_total"] == 12 and e["frames_per_rank"] == [6, 6] and e["results_equal"] is True and e["constants_equal_across_ranks"] is True
 
 
 def test_bench_gpus_2_called_plainly_launches_its_own_ranks():
@@ -164,3 +184,58 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     env2 = dict(env, RIP_BENCH_BACKEND="gloo", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     r = subprocess.run(cmd[:3] + ["2"] + cmd[4:], env=env2, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_config3_sequence_of_64_frames_1920x1200_tracks_the_drifting_tint(gpu_pipe, oracle):
+    """BASELINE configs[2] exactly as SURVEY 8(d) writes it: 64 frames of 1920x1200 bayer_gbrg8 whose tint drifts r 0.70 ->
+    0.80, ccc white balance with temporal consistency, colour enhancer 1.2.  Once as ONE resident batch (the estimator's
+    sequential Kalman step on the device) and once as 64 single calls; in both, for every frame, the RAW argmax of the
+    response, the FILTERED (u, v) the gains are taken at and the gains themselves must equal the oracle's -- the sequence,
+    not only the pixels (convolutional_color_constancy.cpp:273-381) -- and every output frame must equal the oracle's."""
+    import torch
+    w, h, n = 1920, 1200, 64
+    filt, bias = synth.ccc_model()
+    c = cfg(wb=True, wb_method="ccc", wb_bright=0.8, wb_dark=0.2, wb_temporal=True, ce=True, ce_sat=1.2)
+    frames = np.stack([synth.gen_frame(w, h, "bayer_gbrg8", seed=6400 + i, kind="scene", tint=(0.70 + 0.10 * i / (n - 1), 1.0, 0.55))
+                       for i in range(n)])
+    # the oracle's track and images: one filter state walked through the 64 frames
+    occ_track = oracle.CCC(filt, bias)
+    occ_track.set_thresholds(0.8, 0.2)
+    occ_track.set_temporal_consistency(True)
+    occ_track.set_kalman_model(1.0, 10.0)
+    occ_pixels = oracle.CCC(filt, bias)
+    occ_pixels.set_kalman_model(1.0, 10.0)
+    track, gains, refs = [], [], []
+    for i in range(n):
+        _, info, g = occ_track.balance(oracle.debayer(frames[i], "bayer_gbrg8"))
+        track.append(info)
+        gains.append(g)
+        refs.append(oracle_run(oracle, c, frames[i], "bayer_gbrg8", ccc=occ_pixels)[0])
+    track = np.asarray(track, np.int32)
+    gains = np.asarray(gains, np.float32)
+    assert len({tuple(t[2:]) for t in track}) >= 3, "the filtered estimate must follow the drift (else the test shows nothing)"
+    assert (track[:, :2] != track[:, 2:]).any(), "the Kalman filter must lag the raw argmax somewhere"
+
+    gpu_pipe.set_ccc_model(filt, bias)
+    gpu_pipe.set_ccc_kalman_model(1.0, 10.0)
+    configure(gpu_pipe, c)
+    # (a) one resident batch
+    gpu_pipe.reset_white_balance_temporal_consistency()
+    out = gpu_pipe.apply_device(torch.from_numpy(frames).cuda(), "bayer_gbrg8")
+    torch.cuda.synchronize()
+    got_track = gpu_pipe.get_ccc_track(n)
+    got_info = gpu_pipe.get_white_balance_info(n)
+    assert np.array_equal(got_track, track), "batch: (u, v) sequence differs first at frame %d" % int(np.argmax((got_track != track).any(axis=1)))
+    assert np.array_equal(got_info[:, 0:3], gains), "batch: gains differ"
+    out = out.cpu().numpy()
+    for i in range(n):
+        assert_images_equal(out[i], refs[i], "batch frame %d" % i)
+    del out
+    # (b) 64 single calls on the same stream (host frames through process())
+    gpu_pipe.reset_white_balance_temporal_consistency()
+    for i in range(n):
+        got = gpu_pipe.process(frames[i], "bayer_gbrg8")
+        t = gpu_pipe.get_ccc_track(1)[0]
+        assert np.array_equal(t, track[i]), "single calls: frame %d (u, v) %s, oracle %s" % (i, t, track[i])
+        assert np.array_equal(gpu_pipe.get_white_balance_info(1)[0][0:3], gains[i])
+        assert_images_equal(got, refs[i], "single call frame %d" % i)
