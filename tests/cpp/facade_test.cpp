@@ -116,7 +116,12 @@ int main(int argc, char** argv) {
     std::string e3;
     Mat v3 = proc.collectView(proc.submitTo(bayer, "bayer_rggb8", mo, nullptr, &mc), e3);
     if (v3.data != pin_out || std::memcmp(pin_out, out.data, (size_t)w * h * 3) != 0) return fail("submitTo result");
-    if (proc.getDistColorImageView().data != pin_col || std::memcmp(pin_col, col.data, (size_t)w * h * 3) != 0) return fail("submitTo colour tap");
+    if (std::memcmp(pin_col, col.data, (size_t)w * h * 3) != 0) return fail("submitTo colour tap");
+    // the caller's buffers are the caller's again once the ticket is collected (rip.h): the getters must not alias them --
+    // they hand out the image from the slot the frame keeps held, even after the caller has scribbled over its own copy
+    std::memset(pin_col, 0x5a, (size_t)w * h * 3);
+    Mat after = proc.getDistColorImageView();
+    if (after.data == pin_col || after.rows != h || std::memcmp(after.data, col.data, (size_t)w * h * 3) != 0) return fail("getter after submitTo");
     try {  // a pageable destination is refused
       Mat pageable = make_u8(h, w, 3);
       proc.submitTo(bayer, "bayer_rggb8", pageable);

@@ -205,14 +205,17 @@ def test_config3_sequence_of_64_frames_1920x1200_tracks_the_drifting_tint(gpu_pi
     occ_track.set_kalman_model(1.0, 10.0)
     occ_pixels = oracle.CCC(filt, bias)
     occ_pixels.set_kalman_model(1.0, 10.0)
-    track, gains, refs = [], [], []
-    for i in range(n):
-        _, info, g = occ_track.balance(oracle.debayer(frames[i], "bayer_gbrg8"))
-        track.append(info)
-        gains.append(g)
-        refs.append(oracle_run(oracle, c, frames[i], "bayer_gbrg8", ccc=occ_pixels)[0])
-    track = np.asarray(track, np.int32)
-    gains = np.asarray(gains, np.float32)
+
+    def oracle_pass():
+        track, gains, refs = [], [], []
+        for i in range(n):
+            _, info, g = occ_track.balance(oracle.debayer(frames[i], "bayer_gbrg8"))
+            track.append(info)
+            gains.append(g)
+            refs.append(oracle_run(oracle, c, frames[i], "bayer_gbrg8", ccc=occ_pixels)[0])
+        return np.asarray(track, np.int32), np.asarray(gains, np.float32), refs
+
+    track, gains, refs = oracle_pass()
     assert len({tuple(t[2:]) for t in track}) >= 3, "the filtered estimate must follow the drift (else the test shows nothing)"
     assert (track[:, :2] != track[:, 2:]).any(), "the Kalman filter must lag the raw argmax somewhere"
 
@@ -231,8 +234,15 @@ def test_config3_sequence_of_64_frames_1920x1200_tracks_the_drifting_tint(gpu_pi
     for i in range(n):
         assert_images_equal(out[i], refs[i], "batch frame %d" % i)
     del out
-    # (b) 64 single calls on the same stream (host frames through process())
+    # (b) 64 single calls on the same stream (host frames through process()).  resetWhiteBalanceTemporalConsistency only re-arms
+    # first_frame_ (convolutional_color_constancy.cpp:433-435): the error covariance the first pass left behind stays, so the
+    # second pass filters differently from the first -- the oracle's two filters are walked on in the same way
     gpu_pipe.reset_white_balance_temporal_consistency()
+    occ_track.reset()
+    occ_pixels.reset()
+    first_track = track
+    track, gains, refs = oracle_pass()
+    assert not np.array_equal(track, first_track), "the kept covariance must show in the second pass"
     for i in range(n):
         got = gpu_pipe.process(frames[i], "bayer_gbrg8")
         t = gpu_pipe.get_ccc_track(1)[0]

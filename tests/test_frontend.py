@@ -200,8 +200,8 @@ def test_camera_rig_trigger_that_fails_half_way_leaves_no_frame_in_flight(rip_li
     got = rig.on_images(second, ["bayer_rggb8"] * ncam, stamp=2.0, mode="pipelined")
     ref = rig.on_images(second, ["bayer_rggb8"] * ncam, stamp=2.0, mode="sequential")
     for c in range(ncam):
-        a = {m["topic"]: m for m in got[c]}
-        b = {m["topic"]: m for m in ref[c]}
+        a = {m["topic"]: m for m in got[c] if not m["topic"].endswith("slow")}
+        b = {m["topic"]: m for m in ref[c] if not m["topic"].endswith("slow")}
         assert a.keys() == b.keys()
         for t in a:
-            assert a[t]["stamp"] == 2.0 and np.array_equal(a[t]["image"], b[t]["image"]), (c, t)
+            assert a[t]["header"]["stamp"] == 2.0 and np.array_equal(a[t]["image"], b[t]["image"]), (c, t)
