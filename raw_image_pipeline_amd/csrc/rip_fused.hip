@@ -202,23 +202,7 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
         lds_load6(img, tap_addr[k], t0[k], t1[k]);
         lds_load6(img, tap_addr[k] + bp, b0[k], b1[k]);
       }
-      int q[4][3];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned wy0 = wyy[k] & 0xffffu, wy1 = wyy[k] >> 16;
-        const unsigned wB = wxb[k], wx0 = wB & 0xffu, wx1 = wB >> 24;
-        const unsigned wG0 = wx0 << 8, wR0 = wx0 << 16, wR1 = wx1 << 8;
-        const unsigned topB = __builtin_amdgcn_udot4(t0[k], wB, 16u, false);
-        const unsigned topG = __builtin_amdgcn_udot4(t0[k], wG0, __builtin_amdgcn_udot4(t1[k], wx1, 16u, false), false);
-        const unsigned topR = __builtin_amdgcn_udot4(t0[k], wR0, __builtin_amdgcn_udot4(t1[k], wR1, 16u, false), false);
-        const unsigned botB = __builtin_amdgcn_udot4(b0[k], wB, 16u, false);
-        const unsigned botG = __builtin_amdgcn_udot4(b0[k], wG0, __builtin_amdgcn_udot4(b1[k], wx1, 16u, false), false);
-        const unsigned botR = __builtin_amdgcn_udot4(b0[k], wR0, __builtin_amdgcn_udot4(b1[k], wR1, 16u, false), false);
-        q[k][0] = blend_rows(topB, wy0, botB, wy1);
-        q[k][1] = blend_rows(topG, wy0, botG, wy1);
-        q[k][2] = blend_rows(topR, wy0, botR, wy1);
-      }
-      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, pack4(q));
+      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, blend4_bgr(t0, t1, b0, b1, wxb, wyy));
     };
     auto wait_landed = [&](int f) {  // the Bayer bytes of frame f are in LDS (this wave's part): frames issued after f may fly
       const int ahead = min(dist - 1, f_end - 1 - f);

@@ -109,6 +109,49 @@ __device__ __forceinline__ int blend_rows(unsigned top, unsigned wy0, unsigned b
   asm("s_nop 2\n\tv_mul_u32_u24 %0, %1, %2\n\tv_mad_u32_u24 %0, %3, %4, %0" : "=&v"(acc) : "v"(top), "v"(wy0), "v"(bot), "v"(wy1));
   return (int)(acc >> 10);
 }
+// The same sum left unshifted, for row weights the caller has multiplied by 64 (wy0 = 64 (32 - fy), wy1 = 64 fy: still 24-bit
+// operands, the sum stays below 2^24): the result byte (sum >> 10 of the unscaled weights) then IS byte 2 of the accumulator,
+// and four of them are merged into an output dword with two v_perm_b32 and one v_or_b32 (pack_byte2) instead of a shift, a
+// mask and a shift-or per byte.
+__device__ __forceinline__ uint32_t blend_rows_b2(unsigned top, unsigned wy0_64, unsigned bot, unsigned wy1_64) {
+  unsigned acc;
+  asm("s_nop 2\n\tv_mul_u32_u24 %0, %1, %2\n\tv_mad_u32_u24 %0, %3, %4, %0" : "=&v"(acc) : "v"(top), "v"(wy0_64), "v"(bot), "v"(wy1_64));
+  return acc;
+}
+// byte 2 of a, b, c, d -> one dword (a in byte 0)
+__device__ __forceinline__ uint32_t pack_byte2(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  return __builtin_amdgcn_perm(b, a, 0x0c0c0602u) | __builtin_amdgcn_perm(d, c, 0x06020c0cu);
+}
+// Four BGR pixels from their tap rows (t0 / t1: bytes b0 g0 r0 b1 | g1 r1 . . of the top row, b0 / b1 of the bottom row), the x
+// weights wxb = wx0 | wx1 << 24 and the y weights wyy = wy0 | wy1 << 16 (wx0 + wx1 = wy0 + wy1 = 32): cv::remap's
+// ((top (32 - fy) + bot fy) 32 + 2^14) >> 15 per channel, exact in integers; 12 interleaved output bytes.
+// Round 5: six quarter-rate instructions per tap row instead of seven, and the output bytes merged by v_perm_b32.  The two
+// taps of B are bytes 0 and 3 of the realigned dword (one v_dot4, weights wx0 . . wx1); G and R used to take two v_dot4 each
+// (their second tap lies in the next dword) -- one v_perm_b32 with a constant selector gathers g0 r0 g1 r1 into ONE dword, and
+// G and R are a v_dot4 each on it with the weights (wx0 . wx1 .) and (. wx0 . wx1): the same integer sums.  Every row sum
+// starts at 16: 16 (32 - fy) + 16 fy = 512 is the rounding term.
+__device__ __forceinline__ Pack3 blend4_bgr(const uint32_t (&t0)[4], const uint32_t (&t1)[4], const uint32_t (&b0)[4], const uint32_t (&b1)[4],
+                                            const unsigned (&wxb)[4], const unsigned (&wyy)[4]) {
+  uint32_t q[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned wy0 = (wyy[k] & 0xffffu) << 6, wy1 = (wyy[k] >> 16) << 6;        // x 64: blend_rows_b2 (frame-invariant)
+    const unsigned wB = wxb[k];                                                    // wx0 . . wx1
+    const unsigned wG = (wB & 0xffu) | ((wB >> 8) & 0xff0000u), wR = wG << 8;      // wx0 . wx1 .  /  . wx0 . wx1 (frame-invariant)
+    const uint32_t mt = __builtin_amdgcn_perm(t1[k], t0[k], 0x05040201u), mb = __builtin_amdgcn_perm(b1[k], b0[k], 0x05040201u);
+    const unsigned topB = __builtin_amdgcn_udot4(t0[k], wB, 16u, false);
+    const unsigned topG = __builtin_amdgcn_udot4(mt, wG, 16u, false);
+    const unsigned topR = __builtin_amdgcn_udot4(mt, wR, 16u, false);
+    const unsigned botB = __builtin_amdgcn_udot4(b0[k], wB, 16u, false);
+    const unsigned botG = __builtin_amdgcn_udot4(mb, wG, 16u, false);
+    const unsigned botR = __builtin_amdgcn_udot4(mb, wR, 16u, false);
+    q[k][0] = blend_rows_b2(topB, wy0, botB, wy1);
+    q[k][1] = blend_rows_b2(topG, wy0, botG, wy1);
+    q[k][2] = blend_rows_b2(topR, wy0, botR, wy1);
+  }
+  return Pack3{pack_byte2(q[0][0], q[0][1], q[0][2], q[1][0]), pack_byte2(q[1][1], q[1][2], q[2][0], q[2][1]),
+               pack_byte2(q[2][2], q[3][0], q[3][1], q[3][2])};
+}
 __device__ __forceinline__ void lds_load6(const uint8_t* lds, unsigned a, uint32_t& lo, uint32_t& hi) {
   const uint32_t* w = reinterpret_cast<const uint32_t*>(lds + (a & ~3u));
   const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
