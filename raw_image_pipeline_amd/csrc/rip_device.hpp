@@ -956,13 +956,11 @@ __device__ __forceinline__ RowPgq debayer_row_sel(const RowPrep& up, const RowPr
   return RowPgq{__builtin_amdgcn_perm(D4, V, sel), __builtin_amdgcn_perm(X4, C, sel), __builtin_amdgcn_perm(C, H, sel)};
 }
 __device__ __forceinline__ void swap_regs(uint32_t& a, uint32_t& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void debayer_tile_sel(const Window& win, const DemosaicSel& ds, int y0, int x0, int rows, int cols,
-                                                 unsigned long long edge_lanes, Planar (&out)[2]) {
-  RowPrep r[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) r[k] = prep_row(win.w[k][0], win.w[k][1], win.w[k][2]);
-  const RowPgq a = debayer_row_sel(r[0], r[1], r[2], ds.first);
-  const RowPgq c = debayer_row_sel(r[1], r[2], r[3], ds.second);
+// the two rows of a tile from four prepared window rows (r0 = image row y0 - 1), any pattern, mirrored or not; no border rule
+__device__ __forceinline__ void debayer_rows_sel(const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3, const DemosaicSel& ds,
+                                                 Planar (&out)[2]) {
+  const RowPgq a = debayer_row_sel(r0, r1, r2, ds.first);
+  const RowPgq c = debayer_row_sel(r1, r2, r3, ds.second);
   out[0].b = a.p;
   out[0].g = a.g;
   out[0].r = a.q;
@@ -973,6 +971,13 @@ __device__ __forceinline__ void debayer_tile_sel(const Window& win, const Demosa
     swap_regs(out[0].b, out[0].r);
     swap_regs(out[1].b, out[1].r);
   }
+}
+__device__ __forceinline__ void debayer_tile_sel(const Window& win, const DemosaicSel& ds, int y0, int x0, int rows, int cols,
+                                                 unsigned long long edge_lanes, Planar (&out)[2]) {
+  RowPrep r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) r[k] = prep_row(win.w[k][0], win.w[k][1], win.w[k][2]);
+  debayer_rows_sel(r[0], r[1], r[2], r[3], ds, out);
   debayer_fix_edges(y0, x0, rows, cols, out, ds.mirrored != 0, edge_lanes);
 }
 

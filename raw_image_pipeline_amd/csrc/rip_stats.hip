@@ -271,10 +271,15 @@ __global__ __launch_bounds__(kBlock) void stats_fast_kernel(StatsParams p, int c
                     __builtin_amdgcn_raw_buffer_load_b32(src, off_r, row, 0)};
     };
     auto prep = [&](const RawRow& w) { return prep_row(w.l, w.c, w.r); };
+    // round 5: the six byte merges as v_perm_b32 with the pattern's column parity in an SGPR selector (were v_and + v_and_or
+    // pairs and two copies for the row parity), and the wave-level border test without a ballot per row pair: the column test
+    // depends on the lane only and is taken once, the row test is wave-uniform
+    const DemosaicSel ds = demosaic_selectors(p.bayer_ry, p.bayer_rx, 0);
+    const unsigned long long col_edge_lanes = __builtin_amdgcn_ballot_w64(x0 == 0 || x0 + 4 == p.cols);
     auto consume = [&](const RowPrep& r0, const RowPrep& r1, const RowPrep& r2, const RowPrep& r3, int y0) {
       Planar rowpx[2];
-      debayer_rows_any(r0, r1, r2, r3, p.bayer_ry, p.bayer_rx, rowpx);
-      debayer_fix_edges(y0, x0, p.rows, p.cols, rowpx);
+      debayer_rows_sel(r0, r1, r2, r3, ds, rowpx);
+      debayer_fix_edges(y0, x0, p.rows, p.cols, rowpx, false, (y0 == 0 || y0 + 2 == p.rows) ? ~0ull : col_edge_lanes);
       if (!active) return;
 #pragma unroll
       for (int ly = 0; ly < 2; ly++) {
