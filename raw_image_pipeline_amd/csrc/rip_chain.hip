@@ -628,7 +628,9 @@ void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream) 
     // (the 512-thread vignetting variants run ~3 % faster with one chunk per workgroup than with a 768-workgroup persistent grid)
     // a frame or two on the vignetting variants: three persistent workgroups per CU build the 54 KB of tables once each
     // (67.4 us against 70.3 for the whole single-frame call with one workgroup per chunk: tools/probes/graph_probe.py)
-    const int dflt_blocks = nt == kBlock ? 2048 : (p.n_frames <= 2 ? 1536 : 4096);
+    // (round 5 sweep of the memory-rate variant, debayer + gains + matrix + gamma, 256 frames: 1.245 / 1.242 / 1.224 / 1.219 ms at
+    // 1024 / 2048 / 4096 / 8192 persistent workgroups: the cap is 4096 since then)
+    const int dflt_blocks = nt == kBlock ? 4096 : (p.n_frames <= 2 ? 1536 : 4096);
     const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : dflt_blocks) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
     dim3 grid(blocks, frame_groups(p, tn, cap, blocks));

@@ -224,7 +224,7 @@ void launch_remap_plan_build(const RemapPlanBuildParams& p, hipStream_t stream);
 // Launch tunables.  The defaults are the measured optima (sweeps in EXPERIMENTS.md); the environment variables named beside them
 // override them for experiments, and are read ONCE, by tunables_from_env() when a handle is created -- never on a launch path.
 struct Tunables {
-  int chain_blocks = 0;       // RIP_CHAIN_BLOCKS: persistent 256-thread workgroups per launch; 0 = 2048 (4096 for the 512-thread variants)
+  int chain_blocks = 0;       // RIP_CHAIN_BLOCKS: persistent 256-thread workgroups per launch; 0 = 4096
   int chain_frames = 0;       // RIP_CHAIN_FRAMES: frames per item visit; 0 = 16 for the VALU-bound stage sets, 1 for the HBM-bound ones
   int stats_blocks = 2048;    // RIP_STATS_BLOCKS
   int remap_ring = 1;         // RIP_REMAP_RING=0: register-pipelined tiled kernel instead of the LDS-DMA ring
