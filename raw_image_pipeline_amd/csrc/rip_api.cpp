@@ -1113,7 +1113,11 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     c.dst = chain_dst + (size_t)f0 * chain_stride;
     c.dst_step = chain_step;
     c.dst_frame_stride = chain_stride;
-    c.dst_streaming = (!pl.remap && n >= 8) ? 1 : 0;  // non-temporal stores for an image no kernel of this batch reads again (debayer-only, 256 frames: 1.08 against 1.16 ms)
+    // Non-temporal stores for batches: the image is far larger than the L2s, so lines the chain leaves there only get in the
+    // way.  Rounds 3-4 kept them for images no kernel of the batch reads again (debayer-only, 256 frames: 1.08 against 1.16
+    // ms; the remap of that time lost 19 % behind them); with the LDS-DMA ring remap it is the other way round (round 5, config 2:
+    // remap 1.94-1.97 -> 1.83-1.85 ms behind a chain that stores non-temporally) -- tunable chain_nt
+    c.dst_streaming = (n >= 8 && p->tn.chain_nt != 0 && (!pl.remap || p->tn.chain_nt < 0)) ? 1 : 0;
     c.tap = d_tap_deb ? d_tap_deb + (size_t)f0 * tap_frame : nullptr;
     c.tap_frame_stride = tap_frame;
     // overlap_mode 2: only the statistics of this group share the chip with the remap of the previous one; the chain waits
@@ -1280,6 +1284,7 @@ Tunables tunables_from_env() {
   t.remap_per_cu = positive("RIP_REMAP_PER_CU", t.remap_per_cu);
   t.remap_frames = positive("RIP_REMAP_FRAMES", t.remap_frames);
   if (const char* e = std::getenv("RIP_REMAP_FUSED")) t.remap_fused = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RIP_CHAIN_NT")) t.chain_nt = std::atoi(e);
   t.ccc_lds_hist_min = positive("RIP_CCC_LDS_HIST_MIN", t.ccc_lds_hist_min);
   t.overlap_groups = positive("RIP_OVERLAP_GROUPS", t.overlap_groups);
   t.overlap_mode = positive("RIP_OVERLAP_MODE", t.overlap_mode);
@@ -2152,6 +2157,7 @@ rip_status rip_set_tunable(rip_pipeline* p, const char* name, int value) {
     else if (n == "remap_per_cu") t.remap_per_cu = value;
     else if (n == "remap_frames") t.remap_frames = value;
     else if (n == "remap_fused") t.remap_fused = value;
+    else if (n == "chain_nt") t.chain_nt = value;
     else if (n == "remap_tiled") p->use_tiled_remap = value != 0;
     else if (n == "ccc_lds_hist_min") t.ccc_lds_hist_min = value > 0 ? value : dflt.ccc_lds_hist_min;
     else if (n == "overlap_groups") t.overlap_groups = value;

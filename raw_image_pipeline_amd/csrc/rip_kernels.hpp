@@ -232,6 +232,7 @@ struct Tunables {
   int remap_per_cu = 0;       // RIP_REMAP_PER_CU: resident workgroups per CU; 0 = 6 (ring) / 8 (tiled)
   int remap_frames = 0;       // RIP_REMAP_FRAMES: frames per tile visit (0: by the size of a source frame, 4 .. 12)
   int remap_fused = 1;        // RIP_REMAP_FUSED=0: never run the chain inside the remap's tiles (rip_fused.hip)
+  int chain_nt = -1;          // RIP_CHAIN_NT: non-temporal stores of the fused chain for batches of >= 8 frames; -1 = always (round 5: also when the remap reads the image back), 0 = never, 1 = only when no kernel of the batch reads the image again (rounds 3-4)
   int ccc_lds_hist_min = 12;  // RIP_CCC_LDS_HIST_MIN: smallest batch that takes the LDS histogram (round 4, with 4 workgroups per frame: ms per batch of 8 / 16 / 32 / 47 frames, atomic kernel vs LDS: 0.069 / 0.093 / 0.142 / 0.191 vs 0.077 / 0.081 / 0.093 / 0.108)
   int overlap_groups = 0;     // RIP_OVERLAP_GROUPS: frame groups a batch is split into on the handle's internal streams (rip_api.cpp run_batch); 0 / 1 = off (the measured optimum)
   int overlap_mode = 1;       // RIP_OVERLAP_MODE: 1 = remap(g) beside stats(g+1) + chain(g+1); 2 = beside stats(g+1) only (the chain waits)
