@@ -8,4 +8,4 @@ export RIP_ROUND=5
 bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
 for f in 16 8; do RIP_CHAIN_FRAMES=$f python tools/collect_pmc_sq.py $out/sq$f config2 > /dev/null 2>&1; echo "# RIP_CHAIN_FRAMES=$f"; cat $out/sq$f/pmc_sq_summary.txt; done > $out/two_point.txt 2>&1
 python tools/collect_pmc_any.py $out config2 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_CMD_FIFO_FULL > $out/lds_config2.log 2>&1
-/usr/bin/time -f "default bench.py wall time %e s" python bench.py 2>$out/bench_time.txt | tail -1 > $out/bench_default.json; tail -1 $out/bench_time.txt; python tools/bench_summary.py < $out/bench_default.json
+s=$(date +%s); python bench.py 2>/dev/null | tail -1 > $out/bench_default.json; e=$(date +%s); echo "default bench.py wall time $((e-s)) s" | tee $out/bench_time.txt; python tools/bench_summary.py < $out/bench_default.json
