@@ -95,7 +95,10 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
       cm.split((int)i, r, cc16);
       goff[j] = i < total ? __umul24((unsigned)(BY0 + r), step) + CX0 + ((unsigned)cc16 << 4) : 0xFFFFFFF0u;
     }
-    const unsigned bp = (unsigned)(X1 - X0) * 3u;  // bytes per row of the LDS colour image (a multiple of 12)
+    // bytes per row of the LDS colour image: FOUR bytes per pixel (b g r x) since round 5 -- a tap row of the gather is then two
+    // whole dwords (one aligned 8-byte read, no v_alignbyte) instead of six bytes at any alignment (three dwords); + 8 so that
+    // the rows of a wave, whose lanes read dword pairs four dwords apart, alternate between the two halves of every bank quad
+    const unsigned bp = (unsigned)(X1 - X0) * 4u + 8u;
     unsigned tap_addr[4], wxb[4], wyy[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -103,15 +106,15 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
       const bool live = w < kPlanBorder;
       const unsigned relx = w & 0x7ffu, rely = (w >> 11) & 0x7ffu, fx = (w >> 22) & 31u, fy = w >> 27;
       if (!flip) {
-        tap_addr[k] = live ? __umul24(rely + (unsigned)(ry0 - Y0), bp) + (relx + (unsigned)(rx0 - X0)) * 3u : 0u;
-        wxb[k] = live ? (32u - fx) | (fx << 24) : 0u;
+        tap_addr[k] = live ? __umul24(rely + (unsigned)(ry0 - Y0), bp) + (relx + (unsigned)(rx0 - X0)) * 4u : 0u;
+        wxb[k] = live ? (32u - fx) | (fx << 8) : 0u;
         wyy[k] = (32u - fy) | (fy << 16);
       } else {
         // the tap square {y, y + 1} x {x, x + 1} of the image is the frame square whose top-left pixel is
         // (rows - 2 - y, cols - 2 - x), read upside down and mirrored: the weights change places
         const int sy = b.rows - 2 - (d.y0 + (int)rely), sx = b.cols - 2 - (d.x0 + (int)relx);
-        tap_addr[k] = live ? __umul24((unsigned)(sy - Y0), bp) + (unsigned)(sx - X0) * 3u : 0u;
-        wxb[k] = live ? fx | ((32u - fx) << 24) : 0u;
+        tap_addr[k] = live ? __umul24((unsigned)(sy - Y0), bp) + (unsigned)(sx - X0) * 4u : 0u;
+        wxb[k] = live ? fx | ((32u - fx) << 8) : 0u;
         wyy[k] = fy | ((32u - fy) << 16);
       }
     }
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
       e.lr = (e.x >= 4 ? 4u : 0u) | ((e.x + 4 < b.cols ? 4u : 0u) << 16);
 #pragma unroll
       for (int r = 0; r < 4; r++) e.row[r] = __umul24((unsigned)(clampi(e.y - 1 + r, 0, b.rows - 1) - BY0), lp) + (unsigned)e.x - CX0;
-      e.out = __umul24((unsigned)(e.y - Y0), bp) + (unsigned)(e.x - X0) * 3u;
+      e.out = __umul24((unsigned)(e.y - Y0), bp) + (unsigned)(e.x - X0) * 4u;
       return e;
     };
     const Item item0 = make_item(tid < n_items ? tid : 0);
@@ -162,10 +165,15 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
 #pragma unroll
       for (int ly = 0; ly < 2; ly++) {
         Planar v = rowpx[ly];
-        Pack3 o;
+        uint32_t px[4];  // b | g << 8 | r << 16 | (anything) << 24
         if (BITS == 0 && WB == WB_NONE) {
-          interleave4(v, o.a, o.b, o.c);
+          const uint32_t bg01 = __builtin_amdgcn_perm(v.g, v.b, 0x05010400u), bg23 = __builtin_amdgcn_perm(v.g, v.b, 0x07030602u);  // B0 G0 B1 G1 / B2 G2 B3 G3
+          px[0] = __builtin_amdgcn_perm(v.r, bg01, 0x0c040100u);
+          px[1] = __builtin_amdgcn_perm(v.r, bg01, 0x0c050302u);
+          px[2] = __builtin_amdgcn_perm(v.r, bg23, 0x0c060100u);
+          px[3] = __builtin_amdgcn_perm(v.r, bg23, 0x0c070302u);
         } else {
+          Pack3 o;
           if (WB == WB_Q8) {
             v.b = gains_q8_swar(v.b, (unsigned)w.q8[0]);
             v.g = gains_q8_swar(v.g, (unsigned)w.q8[1]);
@@ -179,11 +187,15 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
             q[k][2] = (int)((v.r >> (8 * k)) & 0xFFu);
           }
           o = pointwise4<BITS, WB == WB_Q8 ? WB_NONE : WB>(c, w, tb, cc, hr, ones, q);
+          // twelve interleaved bytes -> four pixels of four bytes; byte 3 of each is whatever follows (the gather never weighs it)
+          px[0] = o.a;
+          px[1] = __builtin_amdgcn_alignbyte(o.b, o.a, 3);
+          px[2] = __builtin_amdgcn_alignbyte(o.c, o.b, 2);
+          px[3] = o.c >> 8;
         }
-        uint32_t* out = reinterpret_cast<uint32_t*>(img + e.out + (ly ? bp : 0u));
-        out[0] = o.a;
-        out[1] = o.b;
-        out[2] = o.c;
+        uint2* out = reinterpret_cast<uint2*>(img + e.out + (ly ? bp : 0u));  // 8-byte aligned: bp and 16 * column are multiples of 8
+        out[0] = make_uint2(px[0], px[1]);
+        out[1] = make_uint2(px[2], px[3]);
       }
     };
     // Bayer stage -> LDS colour image: the fused chain's item (4 px x 2 rows), its window read from LDS instead of HBM
@@ -196,15 +208,19 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
     };
     auto gather_store = [&](const uint8_t* img, int f) {
       if (!in_image) return;
-      uint32_t t0[4], t1[4], b0[4], b1[4];  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
+      uint32_t t0[4], t1[4], b0[4], b1[4];  // left / right pixel (b g r x) of the top / bottom tap rows
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        lds_load6(img, tap_addr[k], t0[k], t1[k]);
-        lds_load6(img, tap_addr[k] + bp, b0[k], b1[k]);
+        const uint32_t* top = reinterpret_cast<const uint32_t*>(img + tap_addr[k]);
+        const uint32_t* bot = reinterpret_cast<const uint32_t*>(img + tap_addr[k] + bp);
+        t0[k] = top[0];
+        t1[k] = top[1];
+        b0[k] = bot[0];
+        b1[k] = bot[1];
       }
       // non-temporal: the final image, nobody on the device reads it again (round 5: 3.134 -> 3.055 ms per 256 frames at 3840 x 2160;
       // the same bit on the two-kernel remap of config 2, which pulls three times the bytes through the L2s, costs it 14 %)
-      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, blend4_bgr(t0, t1, b0, b1, wxb, wyy), true);
+      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, blend4_bgrx(t0, t1, b0, b1, wxb, wyy), true);
     };
     auto wait_landed = [&](int f) {  // the Bayer bytes of frame f are in LDS (this wave's part): frames issued after f may fly
       const int ahead = min(dist - 1, f_end - 1 - f);
@@ -356,7 +372,7 @@ bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max
   const int pre = bayer_chunks <= 1u * kRemapTileThreads ? 1 : (bayer_chunks <= 2u * kRemapTileThreads ? 2 : 4);
   const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
   // one colour image (+ the tap reads' overrun), 16-byte granules; two of them: frame f + 1 is demosaiced while frame f is gathered
-  const unsigned bgr_bytes = ((((unsigned)max_rect_w + 6u) * 3u) * ((unsigned)max_rect_h + 2u) + 32u + 15u) & ~15u;
+  const unsigned bgr_bytes = ((((unsigned)max_rect_w + 6u) * 4u + 8u) * ((unsigned)max_rect_h + 2u) + 32u + 15u) & ~15u;  // four bytes per pixel + 8 per row (kernel: bp)
   RemapTiledParams q = p;
   q.stages = std::max(2, std::min(4, tn.remap_stages));
   const unsigned bgr_off = (unsigned)q.stages * stage_bytes;

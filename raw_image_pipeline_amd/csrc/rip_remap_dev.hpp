@@ -152,6 +152,33 @@ __device__ __forceinline__ Pack3 blend4_bgr(const uint32_t (&t0)[4], const uint3
   return Pack3{pack_byte2(q[0][0], q[0][1], q[0][2], q[1][0]), pack_byte2(q[1][1], q[1][2], q[2][0], q[2][1]),
                pack_byte2(q[2][2], q[3][0], q[3][1], q[3][2])};
 }
+// The same for taps read from an image of FOUR bytes per pixel (b g r x: the colour image the chain-inside-remap kernel keeps in
+// LDS, rip_fused.hip): a tap row is two whole dwords (d0 = left pixel, d1 = right pixel) -- one aligned 8-byte LDS read, no
+// realignment -- and two v_perm_b32 transpose them into b0 b1 g0 g1 and r0 r1 . ., so that every channel is one v_dot4 with the
+// weights w01 = wx0 | wx1 << 8 (B, R) or w01 << 16 (G): five quarter-rate instructions per tap row.  The x bytes never meet a
+// non-zero weight.
+__device__ __forceinline__ Pack3 blend4_bgrx(const uint32_t (&t0)[4], const uint32_t (&t1)[4], const uint32_t (&b0)[4], const uint32_t (&b1)[4],
+                                             const unsigned (&w01)[4], const unsigned (&wyy)[4]) {
+  uint32_t q[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned wy0 = (wyy[k] & 0xffffu) << 6, wy1 = (wyy[k] >> 16) << 6;  // x 64: blend_rows_b2 (frame-invariant)
+    const unsigned wL = w01[k], wH = w01[k] << 16;                            // wx0 wx1 . .  /  . . wx0 wx1 (frame-invariant)
+    const uint32_t tbg = __builtin_amdgcn_perm(t1[k], t0[k], 0x05010400u), tr = __builtin_amdgcn_perm(t1[k], t0[k], 0x0c0c0602u);
+    const uint32_t bbg = __builtin_amdgcn_perm(b1[k], b0[k], 0x05010400u), br = __builtin_amdgcn_perm(b1[k], b0[k], 0x0c0c0602u);
+    const unsigned topB = __builtin_amdgcn_udot4(tbg, wL, 16u, false);
+    const unsigned topG = __builtin_amdgcn_udot4(tbg, wH, 16u, false);
+    const unsigned topR = __builtin_amdgcn_udot4(tr, wL, 16u, false);
+    const unsigned botB = __builtin_amdgcn_udot4(bbg, wL, 16u, false);
+    const unsigned botG = __builtin_amdgcn_udot4(bbg, wH, 16u, false);
+    const unsigned botR = __builtin_amdgcn_udot4(br, wL, 16u, false);
+    q[k][0] = blend_rows_b2(topB, wy0, botB, wy1);
+    q[k][1] = blend_rows_b2(topG, wy0, botG, wy1);
+    q[k][2] = blend_rows_b2(topR, wy0, botR, wy1);
+  }
+  return Pack3{pack_byte2(q[0][0], q[0][1], q[0][2], q[1][0]), pack_byte2(q[1][1], q[1][2], q[2][0], q[2][1]),
+               pack_byte2(q[2][2], q[3][0], q[3][1], q[3][2])};
+}
 __device__ __forceinline__ void lds_load6(const uint8_t* lds, unsigned a, uint32_t& lo, uint32_t& hi) {
   const uint32_t* w = reinterpret_cast<const uint32_t*>(lds + (a & ~3u));
   const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
