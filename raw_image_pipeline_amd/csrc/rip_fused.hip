@@ -28,6 +28,10 @@ namespace {
 #endif
 // LDS image of the visit's per-frame gains (FrameWb is read by every lane of every frame: one global read per visit)
 constexpr int kFusedMaxFrames = 16;
+#ifndef RIP_FUSED_PAD
+#define RIP_FUSED_PAD 8
+#endif
+constexpr unsigned kFusedRowPad = RIP_FUSED_PAD;  // bytes added to every row of the LDS colour image (a multiple of 8)
 
 // s_waitcnt for this wave's LDS writes, then the workgroup barrier: the raw s_barrier builtin does not wait for them, and a
 // __syncthreads() would also drain vmcnt, i.e. the ring's prefetched frames
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
     // bytes per row of the LDS colour image: FOUR bytes per pixel (b g r x) since round 5 -- a tap row of the gather is then two
     // whole dwords (one aligned 8-byte read, no v_alignbyte) instead of six bytes at any alignment (three dwords); + 8 so that
     // the rows of a wave, whose lanes read dword pairs four dwords apart, alternate between the two halves of every bank quad
-    const unsigned bp = (unsigned)(X1 - X0) * 4u + 8u;
+    const unsigned bp = (unsigned)(X1 - X0) * 4u + kFusedRowPad;
     unsigned tap_addr[4], wxb[4], wyy[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -372,7 +376,7 @@ bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max
   const int pre = bayer_chunks <= 1u * kRemapTileThreads ? 1 : (bayer_chunks <= 2u * kRemapTileThreads ? 2 : 4);
   const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
   // one colour image (+ the tap reads' overrun), 16-byte granules; two of them: frame f + 1 is demosaiced while frame f is gathered
-  const unsigned bgr_bytes = ((((unsigned)max_rect_w + 6u) * 4u + 8u) * ((unsigned)max_rect_h + 2u) + 32u + 15u) & ~15u;  // four bytes per pixel + 8 per row (kernel: bp)
+  const unsigned bgr_bytes = ((((unsigned)max_rect_w + 6u) * 4u + kFusedRowPad) * ((unsigned)max_rect_h + 2u) + 32u + 15u) & ~15u;  // four bytes per pixel + 8 per row (kernel: bp)
   RemapTiledParams q = p;
   q.stages = std::max(2, std::min(4, tn.remap_stages));
   const unsigned bgr_off = (unsigned)q.stages * stage_bytes;
@@ -380,7 +384,9 @@ bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max
   if (lds > 60u * 1024u) return false;
   if (dry_run) return true;
   const int ntiles = p.tiles_x * p.tiles_y;
-  const int per_cu = std::max(1, std::min(tn.remap_per_cu > 0 ? tn.remap_per_cu : 6, (int)((160u * 1024u) / (lds + 2048u))));
+  // persistent workgroups per CU of the grid -- not clamped to what the LDS lets reside (round 5, 28.6 KB per workgroup = five
+  // resident: a grid of 6 or 7 per CU runs 2.58-2.60 ms per 256 frames at 3840 x 2160 against 2.61-2.62 with 5)
+  const int per_cu = std::max(1, tn.remap_per_cu > 0 ? tn.remap_per_cu : 6);
   int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
   blocks = std::max(8, blocks / 8 * 8);
   // frames per tile visit: the per-tile set-up (item geometry, plan words: a quarter of the traffic at 4 frames per visit)
