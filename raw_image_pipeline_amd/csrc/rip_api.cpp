@@ -67,6 +67,10 @@ struct DevBuf {
     size_t want = bytes + bytes / 8;
     HIP_CHECK(hipMalloc(&ptr, want));
     cap = want;
+    // RIP_TRACE_ALLOC=1: one line per device allocation on stderr (tools/probes/remap_modes_probe.py relates the per-process
+    // modes of the remap's duration to where its buffers landed)
+    static const bool trace = std::getenv("RIP_TRACE_ALLOC") != nullptr;
+    if (trace) std::fprintf(stderr, "rip alloc %zu bytes at %p\n", want, ptr);
   }
   void release() {
     if (ptr) (void)hipFree(ptr);

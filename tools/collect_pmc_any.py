@@ -25,8 +25,16 @@ def main():
             if m:
                 per.setdefault(m.group(1), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     med = lambda v: sorted(v)[len(v) // 2] if v else 0.0
+    # the same run's kernel trace: median duration per kernel (counter collection serialises the launches but does not change
+    # where the buffers landed -- tools/probes/remap_modes_probe.py)
+    dur = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            m = re.search(r"(\w+_kernel)", row["Kernel_Name"])
+            if m:
+                dur.setdefault(m.group(1), []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
     for k, c in sorted(per.items()):
-        print("%-8s %-24s " % (wl, k) + "  ".join("%s=%.4g" % (n, med(c.get(n, []))) for n in counters), flush=True)
+        print("%-8s %-24s %8.4f ms  " % (wl, k, med(dur.get(k, []))) + "  ".join("%s=%.4g" % (n, med(c.get(n, []))) for n in counters), flush=True)
 
 
 if __name__ == "__main__":
