@@ -10,7 +10,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "librip_oracle.so")
+# RIP_ORACLE_ASAN=1: the sanitizer build of the oracle (`make -C oracle asan`, clang's ASan + UBSan; the process needs
+# LD_PRELOAD of clang's shared ASan runtime -- tools/run_asan.sh sets both)
+_ASAN = os.environ.get("RIP_ORACLE_ASAN", "") == "1"
+_SO = os.path.join(_HERE, "_build", "librip_oracle_asan.so" if _ASAN else "librip_oracle.so")
 
 BAYER = {"bayer_rggb8": 0, "bayer_grbg8": 1, "bayer_gbrg8": 2, "bayer_bggr8": 3}
 WB_METHODS = {"simple": 0, "grey_world": 1, "gray_world": 1, "learned": 2, "ccc": 3, "pca": 4}
@@ -23,7 +26,7 @@ def build(force=False):
     if (not force and os.path.exists(_SO)
             and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return _SO
-    subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    subprocess.run(["make", "-C", _HERE, "-B"] + (["asan"] if _ASAN else []), check=True, capture_output=True)
     return _SO
 
 

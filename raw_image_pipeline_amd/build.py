@@ -37,9 +37,31 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False, out=None, extra_flags=None, tag=""):
+# --asan: the HOST layer (rip_host.cpp, rip_api.cpp: YAML reader, loaders, table builders, frame ring, copy threads) under
+# AddressSanitizer + UndefinedBehaviorSanitizer (clang's runtime, shared, so that python can LD_PRELOAD it); the device
+# code is compiled as always (hipcc ignores -fsanitize for gfx950 without xnack+).  tools/README.md "Sanitizer build".
+ASAN_OUT = os.path.join(HERE, "librip_hip_asan.so")
+ASAN_HOST_FLAGS = ["-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-shared-libsan", "-Wno-option-ignored"]
+
+
+def asan_runtime():
+    """Path of clang's shared ASan runtime (the LD_PRELOAD a python process needs to load librip_hip_asan.so)."""
+    r = subprocess.run([hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], stdout=subprocess.PIPE, text=True)
+    path = r.stdout.strip()
+    if not os.path.isabs(path):
+        import glob
+        cands = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+        path = cands[0] if cands else path
+    return path
+
+
+def build(force=False, verbose=False, out=None, extra_flags=None, tag="", asan=False):
     """out / extra_flags / tag: A/B variants for experiments (tools/ab_chain.py), e.g. extra_flags=["-DRIP_X=1"],
     out=".../variants/x.so"; the default build takes no extra flags beyond $RIP_EXTRA_FLAGS."""
+    if asan:
+        out, tag = out or ASAN_OUT, tag or "_asan"
+        if not force and os.path.exists(out) and all(os.path.getmtime(os.path.join(CSRC, d)) <= os.path.getmtime(out) for d in SOURCES + HEADERS):
+            return out
     if out is None and not force and up_to_date():
         return OUT
     out = out or OUT
@@ -49,7 +71,8 @@ def build(force=False, verbose=False, out=None, extra_flags=None, tag=""):
     os.makedirs(bdir, exist_ok=True)
     for s, fc in [(s, 0) for s in SOURCES] + [(s, 1) for s in FC1_SOURCES]:
         obj = os.path.join(bdir, os.path.splitext(s)[0] + ("_fc1" if fc else "") + ".o")
-        cmd = [hipcc()] + FLAGS + os.environ.get("RIP_EXTRA_FLAGS", "").split() + list(extra_flags or []) + PER_SOURCE_FLAGS.get(s, []) + (["-DRIP_FP_CONTRACT=1"] if fc else []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        san = ASAN_HOST_FLAGS if asan and s.endswith(".cpp") else []
+        cmd = [hipcc()] + FLAGS + san + os.environ.get("RIP_EXTRA_FLAGS", "").split() + list(extra_flags or []) + PER_SOURCE_FLAGS.get(s, []) + (["-DRIP_FP_CONTRACT=1"] if fc else []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -60,7 +83,7 @@ def build(force=False, verbose=False, out=None, extra_flags=None, tag=""):
             raise RuntimeError("hipcc failed on %s:\n%s" % (s, log))
         if verbose and log.strip():
             print(log)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + (["-fsanitize=address,undefined", "-shared-libsan"] if asan else []) + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
@@ -68,4 +91,6 @@ def build(force=False, verbose=False, out=None, extra_flags=None, tag=""):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv))
+    if "--asan" in sys.argv:
+        print("LD_PRELOAD=" + asan_runtime())

@@ -68,9 +68,14 @@ std::vector<std::string> split_flow(const std::string& body, int line_no) {
   return out;
 }
 
+// Nesting the reader follows (both parsers recurse once per level; a document nested deeper than any configuration file of
+// the reference -- three levels -- by an order of magnitude is refused instead of overflowing the stack: tests/test_host_fuzz.py)
+constexpr int kMaxYamlDepth = 64;
+
 // flow map starting at text[at] == '{'; leaves `at` behind the closing brace
-void parse_flow_map(const std::string& text, size_t& at, int line_no, YamlNode& node) {
+void parse_flow_map(const std::string& text, size_t& at, int line_no, YamlNode& node, int depth = 0) {
   auto fail = [&](const char* what) { throw YamlError(std::string("yaml: ") + what + " (line " + std::to_string(line_no) + ")"); };
+  if (depth > kMaxYamlDepth) fail("flow maps nested too deeply");
   auto skip_ws = [&]() { while (at < text.size() && (text[at] == ' ' || text[at] == '\t')) at++; };
   node.kind = YamlNode::Map;
   at++;  // '{'
@@ -86,7 +91,7 @@ void parse_flow_map(const std::string& text, size_t& at, int line_no, YamlNode& 
     skip_ws();
     YamlNode child;
     if (at < text.size() && text[at] == '{') {
-      parse_flow_map(text, at, line_no, child);
+      parse_flow_map(text, at, line_no, child, depth + 1);
     } else if (at < text.size() && text[at] == '[') {
       size_t close = text.find(']', at);
       if (close == std::string::npos) fail("unterminated '[' in flow map");
@@ -111,8 +116,9 @@ void parse_flow_map(const std::string& text, size_t& at, int line_no, YamlNode& 
 }
 
 // parses lines[pos..) with indentation == indent into `node` (a map)
-void parse_block(const std::vector<Line>& lines, size_t& pos, int indent, YamlNode& node) {
+void parse_block(const std::vector<Line>& lines, size_t& pos, int indent, YamlNode& node, int depth = 0) {
   node.kind = YamlNode::Map;
+  if (depth > kMaxYamlDepth) throw YamlError("yaml: blocks nested too deeply at line " + std::to_string(pos < lines.size() ? lines[pos].number : 0));
   while (pos < lines.size()) {
     const Line& ln = lines[pos];
     if (ln.indent < indent) return;
@@ -138,7 +144,7 @@ void parse_block(const std::vector<Line>& lines, size_t& pos, int indent, YamlNo
     YamlNode child;
     if (val.empty()) {
       if (pos < lines.size() && lines[pos].indent > indent) {
-        parse_block(lines, pos, lines[pos].indent, child);
+        parse_block(lines, pos, lines[pos].indent, child, depth + 1);
       }  // else: null
     } else if (val[0] == '[') {
       std::string body = val.substr(1);

@@ -192,6 +192,7 @@ struct RemapTiledParams {
   // table (the gamma LUT; null = none) and / or are addressed in the 180-degree-flipped frame -- the whole mono8 chain
   const uint8_t* mono_lut;
   int mono_flip180;
+  int exp;                     // timing-only experiment switches (Tunables::remap_exp); read by -DRIP_EXPERIMENTS builds only
 };
 
 // Fisheye maps on the device (rip_maps.hip): iR = (P R)^-1 from the host, K / D of the distorted camera.
@@ -231,6 +232,7 @@ struct Tunables {
   int remap_stages = 3;       // RIP_REMAP_STAGES: LDS ring size
   int remap_per_cu = 0;       // RIP_REMAP_PER_CU: resident workgroups per CU; 0 = 6 (ring) / 8 (tiled)
   int remap_frames = 0;       // RIP_REMAP_FRAMES: frames per tile visit (0: by the size of a source frame, 4 .. 12)
+  int remap_exp = 0;          // RIP_REMAP_EXP: bit mask of timing-only experiments (wrong pixels), honoured by -DRIP_EXPERIMENTS builds only (tools/probes/remap_exp_probe.py)
   int remap_fused = 1;        // RIP_REMAP_FUSED=0: never run the chain inside the remap's tiles (rip_fused.hip)
   int chain_nt = -1;          // RIP_CHAIN_NT: non-temporal stores of the fused chain for batches of >= 8 frames; -1 = always (round 5: also when the remap reads the image back), 0 = never, 1 = only when no kernel of the batch reads the image again (rounds 3-4)
   int ccc_lds_hist_min = 12;  // RIP_CCC_LDS_HIST_MIN: smallest batch that takes the LDS histogram (round 4, with 4 workgroups per frame: ms per batch of 8 / 16 / 32 / 47 frames, atomic kernel vs LDS: 0.069 / 0.093 / 0.142 / 0.191 vs 0.077 / 0.081 / 0.093 / 0.108)

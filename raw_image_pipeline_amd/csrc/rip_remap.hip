@@ -6,6 +6,7 @@
 
 namespace rip {
 namespace {
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // 4 destination pixels per thread (CN == 3, dcols % 4 == 0, dword-aligned pitch)
 __global__ __launch_bounds__(kBlock) void remap_vec4_kernel(RemapParams p, ItemMap im, int items_per_frame) {
@@ -245,12 +246,36 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(lds);
   const unsigned wave_chunk0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);
   const unsigned dst_bytes = __umul24((unsigned)(b.drows - 1), (unsigned)b.dst_step) + (unsigned)b.dcols * (unsigned)CN;
+#ifdef RIP_EXPERIMENTS
+  // timing-only switches (wrong pixels): 1 no per-frame barrier, 2 tile-linear stores, 4 tile-linear source loads,
+  // 8 no gather (LDS reads + arithmetic), 16 no stores, 32 no source loads, 64 no plan words (synthesised),
+  // 128 the counted waits leave the two youngest stores out (PRE + 2 operations may be in flight), 256 stores as 16-byte lanes
+  // (lanes < 192) at tile-linear positions, 512 stores as 16-byte lanes at the tile's row-major positions (12 lanes per row)
+  const int ex = __builtin_amdgcn_readfirstlane(p.exp);
+#else
+  constexpr int ex = 0;
+#endif
   for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
-    const int tile = xcd * per_xcd + ti;
+    int tile = xcd * per_xcd + ti;
+#ifdef RIP_EXPERIMENTS
+    {  // bits 12..15: how the tiles are dealt to the XCDs -- 0 one contiguous range each, 1 single tiles round-robin, 2 / 3 / 4 runs of 39 / 13 / 78 tiles round-robin
+      const int mm = (ex >> 12) & 15;
+      const int run = mm == 1 ? 1 : (mm == 2 ? p.tiles_x : (mm == 3 ? 13 : (mm == 4 ? 2 * p.tiles_x : 0)));
+      if (run) tile = ((ti / run) * 8 + xcd) * run + ti % run;
+      if (run && tile >= ntiles) continue;
+    }
+#endif
     if (tile >= ntiles) break;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const RemapTileDesc d = p.tiles[tile];
-    const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * kRemapTilePx)[tid];
+    uint4 wd;
+    if (ex & 64) {
+      const unsigned r0 = (unsigned)(tid / kRemapGroupsPerRow), c0 = (unsigned)(tid % kRemapGroupsPerRow) * 4u;
+      const unsigned w0 = (c0 & 0x7ffu) | (r0 << 11) | (5u << 22) | (9u << 27);
+      wd = make_uint4(w0, w0 + 1, w0 + 2, w0 + 3);
+    } else {
+      wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * kRemapTilePx)[tid];
+    }
     const uint32_t words[4] = {wd.x, wd.y, wd.z, wd.w};
     const int yd = ty * kRemapTileH + lrow, xd = tx * kRemapTileW + lgrp * 4;
     const bool in_image = yd < b.drows && xd < b.dcols;
@@ -272,6 +297,8 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
       int r, c;
       cm.split((int)i, r, c);
       goff[j] = i < total ? __umul24((unsigned)(oy + r), step) + chunk0 + ((unsigned)c << 4) : 0xFFFFFFF0u;
+      if ((ex & 4) && i < total) goff[j] = ((unsigned)tile * 4608u) % (step * (unsigned)(b.rows - 2)) + (i << 4);
+      if (ex & 32) goff[j] = 0xFFFFFFF0u;
     }
     unsigned tap_addr[4], wxb[4], wyy[4];
 #pragma unroll
@@ -289,7 +316,8 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
         wyy[k] = (32u - fy) | (fy << 16);
       }
     }
-    const unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * (unsigned)CN;
+    unsigned dst_off = __umul24((unsigned)yd, (unsigned)b.dst_step) + (unsigned)xd * (unsigned)CN;
+    if (ex & 2) dst_off = ((unsigned)tile * (unsigned)kRemapTilePx + (unsigned)tid * 4u) * (unsigned)CN % (dst_bytes - 64u) & ~3u;
 
     auto issue = [&](int f, int slot) {
       const RemapSrc s = remap_src(b, f);
@@ -321,12 +349,35 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
         return;
       }
       uint32_t t0[4], t1[4], b0[4], b1[4];  // bytes b0 g0 r0 b1 | g1 r1 . .  of the top / bottom tap rows
+      if (ex & (256 | 512)) {
+        if (tid < 192) {
+          unsigned o16 = (((unsigned)tile * 3072u) % (dst_bytes - 4096u) & ~15u) + (unsigned)tid * 16u;
+          if (ex & 512) o16 = __umul24((unsigned)(ty * kRemapTileH + tid / 12), (unsigned)b.dst_step) + (unsigned)(tx * kRemapTileW) * 3u + (unsigned)(tid % 12) * 16u;
+          u32x4 v4 = {tap_addr[0], wxb[1], wyy[2], tap_addr[3]};
+          if (!(ex & 8)) {
+            uint32_t a0, a1;
+            lds_load6(buf, tap_addr[0], a0, a1);
+            v4[0] = a0; v4[1] = a1;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(v4, frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), (int)o16, 0, 0);
+        }
+        return;
+      }
+      if (ex & 8) {
+        if (!(ex & 16)) store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, Pack3{tap_addr[0], wxb[1], wyy[2]});
+        return;
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         lds_load6(buf, tap_addr[k], t0[k], t1[k]);
         lds_load6(buf, tap_addr[k] + pitch, b0[k], b1[k]);
       }
-      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, blend4_bgr(t0, t1, b0, b1, wxb, wyy));
+      const Pack3 px = blend4_bgr(t0, t1, b0, b1, wxb, wyy);
+      if (ex & 16) {
+        if (px.a == 0x12345678u && px.b == 0x9abcdef0u && px.c == 0x0fedcba9u) store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, px);
+        return;
+      }
+      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, px);
     };
 
     // every earlier memory operation of this wave (plan words, tile descriptor, previous stores) is
@@ -339,13 +390,20 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
     }
     for (int f = f_begin; f < f_end; f++) {
       const int ahead = min(dist - 1, f_end - 1 - f);  // frames issued after f and still allowed in flight
-      if (ahead >= 2)
+      if (ex & 128) {
+        if (ahead >= 2)
+          wait_vmcnt<2 * PRE + 2>();
+        else if (ahead == 1)
+          wait_vmcnt<PRE + 2>();
+        else
+          wait_vmcnt<(PRE + 2 < 2 ? PRE + 2 : 2)>();
+      } else if (ahead >= 2)
         wait_vmcnt<2 * PRE>();
       else if (ahead == 1)
         wait_vmcnt<PRE>();
       else
         wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+      if (!(ex & 1)) __builtin_amdgcn_s_barrier();
       if (f + dist < f_end) {
         issue(f + dist, slot_in);
         slot_in = slot_in + 1 == nb ? 0 : slot_in + 1;
@@ -405,6 +463,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
     const int pre = chunks <= 1u * kRemapTileThreads ? 1 : (chunks <= 2u * kRemapTileThreads ? 2 : 4);
     const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
     q.stages = std::max(2, std::min(4, stages_env));
+    q.exp = tn.remap_exp;
     const unsigned lds = (unsigned)q.stages * stage_bytes + 16u;  // the three-dword tap reads run up to 11 B past a row
     const int per_cu = std::max(1, std::min(tn.remap_per_cu > 0 ? tn.remap_per_cu : 6, (int)((160u * 1024u) / (lds + 256u))));
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);

@@ -158,7 +158,7 @@ class RawImagePipeline:
                                       (calibration_path or "").encode(), (color_calibration_path or "").encode(),
                                       C.byref(self._h))
         if st != RIP_OK:
-            msg = self._lib.rip_last_error(None).decode()
+            msg = self._lib.rip_last_error(None).decode(errors="replace")
             self._h = C.c_void_p()
             self._raise(st, msg)
         self.device = int(device)
@@ -188,7 +188,7 @@ class RawImagePipeline:
 
     def _check(self, st):
         if st != RIP_OK:
-            self._raise(st, self._lib.rip_last_error(self._h).decode())
+            self._raise(st, self._lib.rip_last_error(self._h).decode(errors="replace"))  # a message may quote bytes of a malformed file
 
     def _call(self, name, *args):
         self._check(getattr(self._lib, name)(self._h, *args))
@@ -610,7 +610,7 @@ class RawImagePipeline:
     def _string(self, name):
         buf = C.create_string_buffer(64)
         self._call(name, buf, C.c_size_t(64))
-        return buf.value.decode()
+        return buf.value.decode(errors="replace")
 
     def get_dist_distortion_model(self):
         return self._string("rip_get_dist_distortion_model")

@@ -1,0 +1,38 @@
+#!/bin/bash
+# One entry point for the GPU calls of a round: `gpurun -- bash tools/run_batch.sh <experiment> [args]`.
+# Results land under gpurun_out/r6_<experiment>/ (scratch); what is worth keeping is copied to profiles/ by hand.
+# Rounds 4-5 used one script per call (tools/batches/, kept for the record); round 6 on: one case per experiment here.
+set -u
+exp=${1:?experiment name}; shift
+out=gpurun_out/r6_$exp; mkdir -p $out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+V=raw_image_pipeline_amd/variants
+case $exp in
+  remap_exp)     # timing-only switches of the ring remap, one process / handle / output allocation (EXPERIMENTS.md round 6)
+    RIP_LIBRARY=$V/exp.so python tools/probes/remap_exp_probe.py --masks "${1:-0,1,2,4,6,8,24,16,32,64}" --rounds "${2:-3}" ${3:+--tunable $3} 2>&1 | tee $out/probe${4:-}.log ;;
+  remap_exp2)    # second look: stores only, combinations, residency, small (Infinity-Cache-resident) batches
+    export RIP_LIBRARY=$V/exp.so
+    python tools/probes/remap_exp_probe.py --masks 0,40,42,70,78,72 --rounds 3 2>&1 | tee $out/masks.log
+    python tools/probes/remap_exp_probe.py --masks 0 --rounds 3 --tunable remap_per_cu=4,5,6 2>&1 | tee $out/per_cu.log
+    for b in 4 8 16 32; do python tools/probes/remap_exp_probe.py --masks 0,8 --rounds 2 --steps 20 --batch $b 2>&1 | grep -v "^round" | tee $out/batch$b.log; done ;;
+  remap_exp3)    # are the stores latency-bound behind the in-order counter, or slow as 12-byte lanes?
+    export RIP_LIBRARY=$V/exp.so
+    python tools/probes/remap_exp_probe.py --masks 0,128,40,168,298,552,512,258,640 --rounds 3 2>&1 | tee $out/masks.log ;;
+  remap_exp4)    # occupancy / frames-per-visit scaling of the stores-only, loads-only and complete kernel
+    export RIP_LIBRARY=$V/exp.so
+    python tools/probes/remap_exp_probe.py --masks 40,24,0 --rounds 2 --tunable remap_per_cu=2,3,4,6 2>&1 | grep -v "^round" | tee $out/per_cu.log
+    python tools/probes/remap_exp_probe.py --masks 40,24,0 --rounds 2 --tunable remap_frames=1,2,4,8,16 2>&1 | grep -v "^round" | tee $out/frames.log ;;
+  remap_exp5)    # how the tiles are dealt to the XCDs (bits 12..15 of the mask): stores only, loads only, complete
+    export RIP_LIBRARY=$V/exp.so
+    python tools/probes/remap_exp_probe.py --masks 40,4136,8232,12328,16424,24,4120,8216,12312,16408,0,4096,8192,12288,16384 --rounds 2 2>&1 | grep -v "^round" | tee $out/masks.log ;;
+  suite)         # whole GPU suite + smoke
+    python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
+    python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
+  bench)         # default line (+ any extra bench.py arguments)
+    python bench.py "$@" 2>&1 | tee $out/bench.log ;;
+  ab)            # tools/ab_chain.py run <args>: library variants in separate processes
+    python tools/ab_chain.py run "$@" 2>&1 | tee $out/ab.log ;;
+  sh)            # free-form: the rest of the line is the command
+    bash -c "$*" 2>&1 | tee $out/sh.log ;;
+  *) echo "unknown experiment $exp"; exit 2 ;;
+esac
