@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
   if constexpr ((BITS & ST_CC) != 0) cc.load(c);
   HsvRegs hr = {};
   const int ntiles = p.tiles_x * p.tiles_y;
-  const int per_xcd = (ntiles + 7) / 8;
+  const TileDeal deal(ntiles, p.deal_run);
   const int xcd = blockIdx.x & 7;
   const int tid = threadIdx.x;
   const int lrow = tid / kRemapGroupsPerRow, lgrp = tid % kRemapGroupsPerRow;
@@ -67,9 +67,10 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
   const unsigned dst_bytes = __umul24((unsigned)(b.drows - 1), (unsigned)b.dst_step) + (unsigned)b.dcols * 3u;
   const unsigned src_bytes = __umul24((unsigned)(b.rows - 1), step) + (unsigned)b.cols;
   const float ones[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-  for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
-    const int tile = xcd * per_xcd + ti;
-    if (tile >= ntiles) break;
+  for (int ti = blockIdx.x >> 3; ti < deal.per_xcd; ti += gridDim.x >> 3) {
+    const int tile = deal.tile(ti, xcd);
+    if (tile == -1) continue;
+    if (tile < 0) break;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const RemapTileDesc d = p.tiles[tile];
     const uint4 wd = reinterpret_cast<const uint4*>(p.words + (size_t)tile * kRemapTilePx)[tid];
@@ -379,6 +380,7 @@ bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max
   const unsigned bgr_bytes = ((((unsigned)max_rect_w + 6u) * 4u + kFusedRowPad) * ((unsigned)max_rect_h + 2u) + 32u + 15u) & ~15u;  // four bytes per pixel + 8 per row (kernel: bp)
   RemapTiledParams q = p;
   q.stages = std::max(2, std::min(4, tn.remap_stages));
+  q.deal_run = remap_deal_run(p.tiles_x, p.tiles_y, tn);
   const unsigned bgr_off = (unsigned)q.stages * stage_bytes;
   const unsigned lds = ((bgr_off + 2u * bgr_bytes) + 15u) & ~15u;
   if (lds > 60u * 1024u) return false;

@@ -210,6 +210,9 @@ int YamlNode::get(const std::string& key, int dflt) const {
   const YamlNode& n = (*this)[key];
   double d;
   if (n.kind != Scalar || !parse_double(n.scalar, d)) return dflt;
+  // a value no int holds (1e300, inf, nan): yaml-cpp's as<int>() throws BadConversion, which utils::get (utils.hpp:62-73) lets
+  // through; the conversion itself would be undefined behaviour here (found by the sanitizer run of tests/test_host_fuzz.py)
+  if (!(d >= -2147483648.0 && d <= 2147483647.0)) throw YamlError("yaml: '" + n.scalar + "' for '" + key + "' is not an integer in range");
   return (int)d;
 }
 double YamlNode::get(const std::string& key, double dflt) const {

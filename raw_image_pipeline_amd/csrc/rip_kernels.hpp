@@ -192,6 +192,7 @@ struct RemapTiledParams {
   // table (the gamma LUT; null = none) and / or are addressed in the 180-degree-flipped frame -- the whole mono8 chain
   const uint8_t* mono_lut;
   int mono_flip180;
+  int deal_run;                // set by the launcher (remap_deal_run): tiles per run of the round-robin deal to the XCDs; 0 = one contiguous range per XCD
   int exp;                     // timing-only experiment switches (Tunables::remap_exp); read by -DRIP_EXPERIMENTS builds only
 };
 
@@ -232,6 +233,7 @@ struct Tunables {
   int remap_stages = 3;       // RIP_REMAP_STAGES: LDS ring size
   int remap_per_cu = 0;       // RIP_REMAP_PER_CU: resident workgroups per CU; 0 = 6 (ring) / 8 (tiled)
   int remap_frames = 0;       // RIP_REMAP_FRAMES: frames per tile visit (0: by the size of a source frame, 4 .. 12)
+  int remap_deal = 1;         // RIP_REMAP_DEAL: how the ring kernels deal the tiles to the eight XCDs -- k > 0: runs of about k tile rows round-robin (all XCDs work on one band of the image; round 6: -5 % at 4 frames per visit, -12 % with 8), 0: one contiguous range of tiles per XCD (rounds 1-5)
   int remap_exp = 0;          // RIP_REMAP_EXP: bit mask of timing-only experiments (wrong pixels), honoured by -DRIP_EXPERIMENTS builds only (tools/probes/remap_exp_probe.py)
   int remap_fused = 1;        // RIP_REMAP_FUSED=0: never run the chain inside the remap's tiles (rip_fused.hip)
   int chain_nt = -1;          // RIP_CHAIN_NT: non-temporal stores of the fused chain for batches of >= 8 frames; -1 = always (round 5: also when the remap reads the image back), 0 = never, 1 = only when no kernel of the batch reads the image again (rounds 3-4)
@@ -246,6 +248,8 @@ Tunables tunables_from_env();  // rip_api.cpp; called by rip_create
 // Returns false (and launches nothing) when the geometry does not qualify for the tiled kernel.
 // dry_run: only answer (the API decides with it whether a mono8 chain can be folded into the gather).
 bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream, bool dry_run = false);
+// tiles per run of the round-robin deal (RemapTiledParams::deal_run) for a plan of tiles_x x tiles_y tiles; 0 = contiguous ranges
+int remap_deal_run(int tiles_x, int tiles_y, const Tunables& tn);
 // rip_fused.hip: debayer + memory-rate stages + remap in one kernel over the Bayer frames (p.base.src); false when the
 // configuration / geometry does not qualify (nothing launched).  dry_run: only answer.
 bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max_rect_w, int max_rect_h, const Tunables& tn, hipStream_t stream,

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
   constexpr unsigned kStage = (unsigned)PRE * kRemapTileThreads * 16u;  // bytes per stage
   const RemapParams& b = p.base;
   const int ntiles = p.tiles_x * p.tiles_y;
-  const int per_xcd = (ntiles + 7) / 8;
+  const TileDeal deal(ntiles, p.deal_run);
   const int xcd = blockIdx.x & 7;
   const int tid = threadIdx.x;
   const int lrow = tid / kRemapGroupsPerRow, lgrp = tid % kRemapGroupsPerRow;
@@ -255,17 +255,10 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
 #else
   constexpr int ex = 0;
 #endif
-  for (int ti = blockIdx.x >> 3; ti < per_xcd; ti += gridDim.x >> 3) {
-    int tile = xcd * per_xcd + ti;
-#ifdef RIP_EXPERIMENTS
-    {  // bits 12..15: how the tiles are dealt to the XCDs -- 0 one contiguous range each, 1 single tiles round-robin, 2 / 3 / 4 runs of 39 / 13 / 78 tiles round-robin
-      const int mm = (ex >> 12) & 15;
-      const int run = mm == 1 ? 1 : (mm == 2 ? p.tiles_x : (mm == 3 ? 13 : (mm == 4 ? 2 * p.tiles_x : 0)));
-      if (run) tile = ((ti / run) * 8 + xcd) * run + ti % run;
-      if (run && tile >= ntiles) continue;
-    }
-#endif
-    if (tile >= ntiles) break;
+  for (int ti = blockIdx.x >> 3; ti < deal.per_xcd; ti += gridDim.x >> 3) {
+    const int tile = deal.tile(ti, xcd);
+    if (tile == -1) continue;
+    if (tile < 0) break;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const RemapTileDesc d = p.tiles[tile];
     uint4 wd;
@@ -434,6 +427,14 @@ __global__ __launch_bounds__(kBlock) void remap_generic_kernel(RemapParams p) {
 
 }  // namespace
 
+int remap_deal_run(int tiles_x, int tiles_y, const Tunables& tn) {
+  if (tn.remap_deal <= 0 || tiles_x <= 0 || tiles_y <= 0) return 0;
+  // runs of about remap_deal tile rows, sized so that every XCD gets the same number of runs (a ragged last run at most)
+  const int ntiles = tiles_x * tiles_y;
+  const int runs_per_xcd = (tiles_y + 8 * tn.remap_deal - 1) / (8 * tn.remap_deal);
+  return (ntiles + 8 * runs_per_xcd - 1) / (8 * runs_per_xcd);
+}
+
 bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream_t stream, bool dry_run) {
   const RemapParams& b = p.base;
   if (b.n_frames <= 0) return true;
@@ -464,6 +465,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
     const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
     q.stages = std::max(2, std::min(4, stages_env));
     q.exp = tn.remap_exp;
+    q.deal_run = remap_deal_run(p.tiles_x, p.tiles_y, tn);
     const unsigned lds = (unsigned)q.stages * stage_bytes + 16u;  // the three-dword tap reads run up to 11 B past a row
     const int per_cu = std::max(1, std::min(tn.remap_per_cu > 0 ? tn.remap_per_cu : 6, (int)((160u * 1024u) / (lds + 256u))));
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
@@ -479,7 +481,14 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
     int frames_per_visit = tn.remap_frames;
     if (frames_per_visit <= 0) {
       const unsigned long long frame_bytes = (unsigned long long)b.src_step * (unsigned long long)b.rows;
-      frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(4, ((64ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
+      // round 6, with the round-robin deal (remap_deal; the XCDs no longer drift apart over a long visit), ms per 256 frames at
+      // 4 / 6 / 8 / 10 / 12 / 16 frames per visit: 2448x2048 1.881 / 1.883 / 1.933 / 2.016 / 2.062 / 2.127 (another box: 2.091 /
+      // 1.955 / 1.935 / 1.966 / 1.998 / 2.090); 3840x2160 2.879 / 2.853 / 2.846 / 2.861 / 2.876 / 2.914; 1920x1200 0.806 / 0.744 /
+      // 0.722 / 0.721 / 0.722 / 0.738; 1440x1080 0.567 / 0.514 / 0.509 / 0.507 / 0.509 / 0.521 -- about 96 MB of source frames, 6 .. 12
+      if (tn.remap_deal > 0)
+        frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(6, ((96ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
+      else
+        frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(4, ((64ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
     }
     int groups = std::max((256 * per_cu) / blocks, (b.n_frames + frames_per_visit - 1) / frames_per_visit);
     groups = std::max(1, std::min(b.n_frames, groups));

@@ -214,6 +214,29 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
       : "v"(voffset), "s"(rsrc), "s"(lds_wave_base)
       : "memory");
 }
+// How the persistent workgroups of the ring kernels find their tiles.  Workgroup b runs on XCD b % 8 (observed dispatch order;
+// speed only) and takes the positions ti = b / 8, b / 8 + gridDim.x / 8, ... of that XCD's share.  Rounds 1-5 gave every XCD one
+// contiguous range of tiles (eight bands of the image in flight at once, each marching down on its own).  Round 6: runs of
+// `run` consecutive tiles (about one tile row) are dealt round-robin, so the tiles in flight on the whole chip form ONE band of
+// consecutive tile rows, read and written by all XCDs together -- the same requests, served 5 % faster at 4 frames per visit
+// and 12 % faster with 8 (which the contiguous deal could not use: its XCDs drift apart).  EXPERIMENTS.md "the deal".
+struct TileDeal {
+  int run, per_xcd, ntiles;
+  __device__ __forceinline__ TileDeal(int ntiles_, int run_) : run(run_), ntiles(ntiles_) {
+    per_xcd = run > 0 ? ((ntiles + run - 1) / run + 7) / 8 * run : (ntiles + 7) / 8;
+  }
+  // tile at position ti of XCD xcd; -1: none here (a ragged last run), keep going; -2: past the end of a contiguous range
+  __device__ __forceinline__ int tile(int ti, int xcd) const {
+    if (run > 0) {
+      const int r = ti / run;
+      const int t = (r * 8 + xcd) * run + (ti - r * run);
+      return t < ntiles ? t : -1;
+    }
+    const int t = xcd * per_xcd + ti;
+    return t < ntiles ? t : -2;
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");

@@ -25,6 +25,25 @@ case $exp in
   remap_exp5)    # how the tiles are dealt to the XCDs (bits 12..15 of the mask): stores only, loads only, complete
     export RIP_LIBRARY=$V/exp.so
     python tools/probes/remap_exp_probe.py --masks 40,4136,8232,12328,16424,24,4120,8216,12312,16408,0,4096,8192,12288,16384 --rounds 2 2>&1 | grep -v "^round" | tee $out/masks.log ;;
+  remap_exp6)    # run length of the round-robin deal, and frames per visit / residency under it
+    export RIP_LIBRARY=$V/exp.so
+    python tools/probes/remap_exp_probe.py --masks 0,8192,16384,20480,24576,36864,28672,32768 --rounds 3 2>&1 | grep -v "^round" | tee $out/masks.log
+    python tools/probes/remap_exp_probe.py --masks 16384,24576 --rounds 2 --tunable remap_frames=3,4,5,6,8 2>&1 | grep -v "^round" | tee $out/frames.log
+    python tools/probes/remap_exp_probe.py --masks 16384 --rounds 2 --tunable remap_per_cu=3,4,5,6 2>&1 | grep -v "^round" | tee $out/per_cu.log ;;
+  remap_exp7)    # frames per visit x run length of the deal (and the contiguous deal beside them)
+    export RIP_LIBRARY=$V/exp.so
+    python tools/probes/remap_exp_probe.py --masks 0,8192,16384,24576 --rounds 2 --tunable remap_frames=4,6,8,10,12,16 2>&1 | grep -v "^round" | tee $out/frames.log
+    python tools/probes/remap_exp_probe.py --masks 16384 --rounds 2 --tunable remap_stages=2,3,4 2>&1 | grep -v "^round" | tee $out/stages.log ;;
+  remap_deal)    # the round-robin deal (RIP_REMAP_DEAL) x frames per visit on the four sensor geometries, two-kernel path and config 5's fused kernel
+    for size in 2448x2048 1440x1080 1920x1200 3840x2160; do for deal in 0 1; do
+      echo "== config2 $size deal=$deal"; RIP_REMAP_DEAL=$deal python tools/probes/remap_exp_probe.py --size $size --rounds 2 --tunable remap_frames=${2:-0,4,6,8,10,12,16} 2>&1 | grep "^mask"
+    done; done | tee $out/config2.log
+    for deal in 0 1 2; do
+      echo "== config5 3840x2160 deal=$deal"; RIP_REMAP_DEAL=$deal python tools/probes/remap_exp_probe.py --workload config5 --size 3840x2160 --rounds 2 --tunable remap_frames=8,12,16 2>&1 | grep "^mask"
+    done | tee $out/config5.log
+    python -m pytest tests -m gpu -x -q -k "undist or remap or fused or config" 2>&1 | tail -5 | tee $out/pytest.log ;;
+  asan)          # the host-frame ring, copy threads, rig, fork handling under ASan + UBSan on the GPU box (tools/run_asan.sh)
+    tools/run_asan.sh python -m pytest tests -m gpu -x -q -p no:cacheprovider -k "${1:-submit or collect or ring or rig or thread or fork or pageable or pool or frontend or facade or error or taps or abi}" 2>&1 | tail -40 | tee $out/pytest.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
