@@ -43,7 +43,26 @@ case $exp in
     done | tee $out/config5.log
     python -m pytest tests -m gpu -x -q -k "undist or remap or fused or config" 2>&1 | tail -5 | tee $out/pytest.log ;;
   asan)          # the host-frame ring, copy threads, rig, fork handling under ASan + UBSan on the GPU box (tools/run_asan.sh)
-    tools/run_asan.sh python -m pytest tests -m gpu -x -q -p no:cacheprovider -k "${1:-submit or collect or ring or rig or thread or fork or pageable or pool or frontend or facade or error or taps or abi}" 2>&1 | tail -40 | tee $out/pytest.log ;;
+    tools/run_asan.sh python -m pytest tests -m gpu -x -q -p no:cacheprovider -k "${1:-submit or collect or ring or rig or thread or fork or pageable or pool or frontend or facade or error or taps or abi}" > $out/pytest_full.log 2>&1
+    grep -v "^  File\|^Loading" $out/pytest_full.log | head -c 20000 | tee $out/pytest.log | tail -30 ;;
+  remap_exp8)    # stores: half-line segments? frame stride?  (timing only)
+    export RIP_LIBRARY=$V/exp.so
+    python tools/probes/remap_exp_probe.py --masks 0,1024,40,1064,42 --rounds 3 2>&1 | grep -v "^round" | tee $out/masks.log
+    python tools/probes/remap_exp_probe.py --masks 106,104 --rounds 2 --tunable remap_frames=1,2,4,8,16 2>&1 | grep -v "^round" | tee $out/frames.log ;;
+  remap_stream)  # the ring as one stream of units: parity of everything that gathers, then timing (and the components)
+    python -m pytest tests -m gpu -x -q -k "undist or remap or fused or config or determinism or fuzz" 2>&1 | tail -5 | tee $out/pytest.log
+    python tools/probes/remap_exp_probe.py --rounds 3 --tunable remap_frames=${1:-0,4,6,8,12} 2>&1 | grep "^mask" | tee $out/frames.log
+    RIP_LIBRARY=$V/exp.so python tools/probes/remap_exp_probe.py --masks 0,8,16,32,24,40,64 --rounds 2 2>&1 | grep "^mask" | tee $out/components.log ;;
+  remap_stream2) # per-visit cost of the stream kernel: stores only / loads only / complete against frames per visit
+    export RIP_LIBRARY=$V/exp.so
+    python tools/probes/remap_exp_probe.py --masks 104,88,0 --rounds 2 --tunable remap_frames=1,2,4,8,16 2>&1 | grep "^mask" | tee $out/frames.log
+    python tools/probes/remap_exp_probe.py --masks 0,8,16,32,24,40,64 --rounds 2 2>&1 | grep "^mask" | tee $out/components.log ;;
+  remap_abc)     # one process, one output allocation: HEAD's ring (per-visit), the stream ring with short-lived workgroups, with persistent ones
+    python tools/probes/remap_exp_probe.py --libs head=$V/head.so,short=,pers=,glob= --set short:remap_persistent=0 --set pers:remap_persistent=1 --set glob:remap_persistent=2 --rounds 3 --tunable remap_frames=${1:-4,6,8} 2>&1 | grep "^mask" | tee $out/abc.log ;;
+  mall)          # does the intermediate image survive in the Infinity Cache between chain and remap?  frame groups on two streams (overlap_groups), small enough for it
+    for nt in -1 0; do for mode in 1 2; do
+      echo "== RIP_CHAIN_NT=$nt overlap_mode=$mode"; RIP_CHAIN_NT=$nt RIP_OVERLAP_MODE=$mode python tools/probes/remap_exp_probe.py --rounds 2 --steps 4 --tunable overlap_groups=0,8,16,22,32,43,64 2>&1 | grep "^mask"
+    done; done | tee $out/mall.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
