@@ -520,8 +520,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line's n_gpus must be the number of ranks that ran" % (args.gpus, world))
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
-    if world > 1:
+    # RIP_DIST_FORCE=1 at N = 1: a single-rank communicator, and every multi-rank code path below runs over it (collectives on
+    # device tensors, the scatter's broadcast, the end-to-end leg) -- the rehearsal of the RCCL path a 1-GPU box allows; its
+    # line carries the `multi` / `scatter` records and is not a benchmark line
+    forced = world == 1 and os.environ.get("RIP_DIST_FORCE", "") == "1"
+    dist_on = world > 1 or forced
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     from raw_image_pipeline_amd import RawImagePipeline
@@ -541,7 +548,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -559,7 +566,7 @@ def main():
     own_elapsed = elapsed
     elapsed = sharding.max_over_ranks(elapsed)  # the job is as slow as its slowest rank
     multi = None
-    if world > 1:
+    if dist_on:
         # self-verifying multi-GPU record: every rank's own rate, what the communicator says about itself, and (rank 0,
         # below) the share of the committed single-GPU rate each GPU retains
         multi = {"per_rank_frames_per_s": [round(v, 1) for v in sharding.gather_over_ranks(args.batch * args.steps / own_elapsed)],
@@ -640,7 +647,7 @@ def main():
             pass
 
     scatter = None
-    if world > 1:
+    if dist_on:
         # The only data movement between ranks on this path: the frame scatter when a batch originates on one rank.
         # Timed outside the steady state (it is bounded by the source GPU's xGMI egress) and reported apart.
         # It runs LAST and under a watchdog: the steady-state numbers above are complete at this point, so a point-to-point
@@ -676,7 +683,7 @@ def main():
             mine = sharding.scatter_frames(src_batch, (height, width), device=sc_dev)
             barrier()
             t_sc = sharding.max_over_ranks(time.perf_counter() - t_sc)
-            a, b = sharding.frame_range_of_rank(args.batch, world, 1)
+            a, b = sharding.frame_range_of_rank(args.batch, world, 1 if world > 1 else 0)
             scatter = {"ranks": world, "backend": backend, "frames": args.batch, "frames_per_destination": b - a,
                        "bytes_per_destination": (b - a) * height * width, "seconds": round(t_sc, 6),
                        "GBps_per_destination": round((b - a) * height * width / t_sc / 1e9, 3),
@@ -688,7 +695,7 @@ def main():
         state["done"] = True
         timer.cancel()
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
     if world == 1 and not args.no_pmc:
@@ -770,7 +777,7 @@ def main():
     elif world == 1:
         result["cpu_baseline"] = None
     print(json.dumps(result))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

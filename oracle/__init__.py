@@ -10,8 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RIP_ORACLE_ASAN=1: the sanitizer build of the oracle (`make -C oracle asan`, clang's ASan + UBSan; the process needs
-# LD_PRELOAD of clang's shared ASan runtime -- tools/run_asan.sh sets both)
+# RIP_ORACLE_ASAN=1: the sanitizer build of the oracle (`make -C oracle asan`, gcc's ASan + UBSan; the process needs
+# LD_PRELOAD of GCC's shared ASan runtime -- tools/run_asan.sh sets both)
 _ASAN = os.environ.get("RIP_ORACLE_ASAN", "") == "1"
 _SO = os.path.join(_HERE, "_build", "librip_oracle_asan.so" if _ASAN else "librip_oracle.so")
 

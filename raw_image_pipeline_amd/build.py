@@ -38,21 +38,25 @@ def up_to_date():
 
 
 # --asan: the HOST layer (rip_host.cpp, rip_api.cpp: YAML reader, loaders, table builders, frame ring, copy threads) under
-# AddressSanitizer + UndefinedBehaviorSanitizer (clang's runtime, shared, so that python can LD_PRELOAD it); the device
-# code is compiled as always (hipcc ignores -fsanitize for gfx950 without xnack+).  tools/README.md "Sanitizer build".
+# AddressSanitizer + UndefinedBehaviorSanitizer, compiled with g++ against GCC's runtimes; the device code is compiled by hipcc
+# as always.  (Not clang's runtime: the ROCm build of compiler-rt intercepts hsa_amd_memory_pool_allocate for device-side ASan and
+# aborts the first HIP allocation of a process on a GPU box -- "allocator is trying to allocate 0x400000 bytes" -- without
+# xnack+ code objects.)  tools/README.md "Sanitizer build".
 ASAN_OUT = os.path.join(HERE, "librip_hip_asan.so")
-ASAN_HOST_FLAGS = ["-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-shared-libsan", "-Wno-option-ignored"]
+ASAN_HOST_CXX = os.environ.get("RIP_ASAN_CXX", "g++")
+ASAN_HOST_FLAGS = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__",
+                   "-I/opt/rocm/include", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=undefined,float-cast-overflow",
+                   "-fno-omit-frame-pointer", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+
+
+def _gcc_lib(name):
+    r = subprocess.run([ASAN_HOST_CXX, "-print-file-name=" + name], stdout=subprocess.PIPE, text=True)
+    return os.path.realpath(r.stdout.strip())
 
 
 def asan_runtime():
-    """Path of clang's shared ASan runtime (the LD_PRELOAD a python process needs to load librip_hip_asan.so)."""
-    r = subprocess.run([hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], stdout=subprocess.PIPE, text=True)
-    path = r.stdout.strip()
-    if not os.path.isabs(path):
-        import glob
-        cands = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
-        path = cands[0] if cands else path
-    return path
+    """Path of GCC's shared ASan runtime (the LD_PRELOAD a python process needs to load librip_hip_asan.so)."""
+    return _gcc_lib("libasan.so")
 
 
 def build(force=False, verbose=False, out=None, extra_flags=None, tag="", asan=False):
@@ -71,8 +75,10 @@ def build(force=False, verbose=False, out=None, extra_flags=None, tag="", asan=F
     os.makedirs(bdir, exist_ok=True)
     for s, fc in [(s, 0) for s in SOURCES] + [(s, 1) for s in FC1_SOURCES]:
         obj = os.path.join(bdir, os.path.splitext(s)[0] + ("_fc1" if fc else "") + ".o")
-        san = ASAN_HOST_FLAGS if asan and s.endswith(".cpp") else []
-        cmd = [hipcc()] + FLAGS + san + os.environ.get("RIP_EXTRA_FLAGS", "").split() + list(extra_flags or []) + PER_SOURCE_FLAGS.get(s, []) + (["-DRIP_FP_CONTRACT=1"] if fc else []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        if asan and s.endswith(".cpp"):
+            cmd = [ASAN_HOST_CXX] + ASAN_HOST_FLAGS + list(extra_flags or []) + ["-c", os.path.join(CSRC, s), "-o", obj]
+        else:
+            cmd = [hipcc()] + FLAGS + os.environ.get("RIP_EXTRA_FLAGS", "").split() + list(extra_flags or []) + PER_SOURCE_FLAGS.get(s, []) + (["-DRIP_FP_CONTRACT=1"] if fc else []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -83,7 +89,7 @@ def build(force=False, verbose=False, out=None, extra_flags=None, tag="", asan=F
             raise RuntimeError("hipcc failed on %s:\n%s" % (s, log))
         if verbose and log.strip():
             print(log)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + (["-fsanitize=address,undefined", "-shared-libsan"] if asan else []) + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ([_gcc_lib("libasan.so"), _gcc_lib("libubsan.so"), "-lstdc++", "-lpthread"] if asan else [])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)

@@ -114,8 +114,18 @@ __device__ __forceinline__ void fast_chunks(const ChainParams& p, const ItemMap&
   const int xcd = blockIdx.x & 7;
   const int flip180 = p.flip_angle == 180 ? 1 : 0;
   const DemosaicSel ds = demosaic_selectors(p.bayer_ry, p.bayer_rx, flip180);
-  for (int ci = blockIdx.x >> 3; ci < per_xcd; ci += gridDim.x >> 3) {
-    const int chunk = xcd * per_xcd + ci;
+#ifndef RIP_CHAIN_DEAL
+#define RIP_CHAIN_DEAL 0
+#endif
+  constexpr int kDeal = RIP_CHAIN_DEAL;  // experiment: runs of kDeal chunks dealt round-robin to the XCDs (0: one contiguous range each)
+  const int ci_end = kDeal > 0 ? ((chunks_per_frame + kDeal - 1) / kDeal + 7) / 8 * kDeal : per_xcd;
+  for (int ci = blockIdx.x >> 3; ci < ci_end; ci += gridDim.x >> 3) {
+    int chunk = xcd * per_xcd + ci;
+    if (kDeal > 0) {
+      const int r = ci / kDeal;
+      chunk = (r * 8 + xcd) * kDeal + (ci - r * kDeal);
+      if (chunk >= chunks_per_frame) continue;
+    }
     if (chunk >= chunks_per_frame) break;
     const int item = chunk * NT + threadIdx.x;
     if (item >= items_per_frame) continue;

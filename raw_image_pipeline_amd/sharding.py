@@ -3,8 +3,19 @@ shards by camera stream / by contiguous frame ranges with NO collective on the d
 communication is the trivial frame scatter when a batch originates on one rank, the broadcast of
 per-camera constants, the barrier and the max-over-ranks time of the benchmark -- all through
 torch.distributed (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU tests)."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _solo():
+    """True when there is nobody to talk to: no process group, or a group of one -- unless RIP_DIST_FORCE=1 asks for the
+    collectives to run anyway (a single-rank RCCL communicator on a 1-GPU box: the only way the nccl code paths below --
+    device tensors, dtypes, the calls themselves -- execute before an 8-GPU node does; tests/test_configs_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("RIP_DIST_FORCE", "") != "1"
 
 
 def streams_of_rank(n_streams, world_size, rank):
@@ -27,7 +38,7 @@ def _dev(t):
 
 def max_over_ranks(value):
     """The benchmark's time is the slowest rank's."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _solo():
         return float(value)
     t = _dev(torch.tensor([float(value)], dtype=torch.float64))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -35,7 +46,7 @@ def max_over_ranks(value):
 
 
 def sum_over_ranks(value):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _solo():
         return float(value)
     t = _dev(torch.tensor([float(value)], dtype=torch.float64))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -44,7 +55,7 @@ def sum_over_ranks(value):
 
 def gather_over_ranks(value):
     """Every rank's value, in rank order (all_gather): the per-rank record of the benchmark line."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _solo():
         return [float(value)]
     mine = _dev(torch.tensor([float(value)], dtype=torch.float64))
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
@@ -67,7 +78,7 @@ def communicator_census():
 
 def broadcast_constants(tensor, src=0):
     """Per-camera constants (undistortion maps, LUTs, ccc model spectrum) computed once on `src`."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if not _solo():
         dist.broadcast(tensor, src=src)
     return tensor
 
@@ -79,7 +90,7 @@ def scatter_frames(batch, frame_shape, dtype=torch.uint8, src=0, device=None):
     This is the 'trivial frame scatter' of the north star: it is bounded by the source GPU's xGMI
     egress (7 links x ~153 GB/s), far below the processing rate, so steady-state benchmarks keep the
     frames resident per GPU and report the scatter separately."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _solo():
         return batch
     world, rank = dist.get_world_size(), dist.get_rank()
     n = torch.tensor([batch.shape[0] if rank == src else 0], dtype=torch.int64)

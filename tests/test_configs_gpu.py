@@ -168,6 +168,35 @@ def test_bench_gpus_2_called_plainly_launches_its_own_ranks():
     assert len(j["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in j["per_rank_frames_per_s"])
 
 
+def test_bench_single_rank_rccl_communicator_runs_every_multi_rank_code_path():
+    """every N > 1 rehearsal above goes over gloo with host tensors, so the RCCL path
+    (device tensors through `nccl`) had never executed before the driver's 8-GPU run.  RIP_DIST_FORCE=1 makes
+    `bench.py --gpus 1` open a ONE-rank `nccl` communicator and run the whole multi-rank code over it: barrier,
+    max-over-ranks (all_reduce f64), per-rank rates (all_gather f64), communicator census (all_reduce int64), the scatter's
+    size broadcast (int64) and own-slice copy of uint8 device frames, the end-to-end leg (processing the received shard,
+    checksums through the padded int64 all_gather, maps through broadcast_constants on device tensors).  It cannot show
+    scaling and does not reach isend / recv (one rank has nobody to send to); it does catch a dtype / device / API mistake."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RIP_BENCH_BACKEND")}
+    env.update(RIP_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", "--no-hbm-probe", "--no-pmc"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1
+    c = j["communicator"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["ranks_counted"] == 1 and c["devices"] == [0], c
+    assert j["rccl_ranks"] == 1 and len(j["per_rank_frames_per_s"]) == 1 and j["per_rank_frames_per_s"][0] > 0
+    sc = j["scatter"]
+    assert "error" not in sc, sc
+    assert sc["backend"] == "nccl" and sc["ranks"] == 1 and sc["frames_per_destination"] == 8
+    e = sc["end_to_end"]
+    assert e["frames_total"] == 8 and e["frames_per_rank"] == [8] and e["frames_checked_against_rank0"] == 8
+    assert e["results_equal"] is True and e["constants_equal_across_ranks"] is True
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     """`--gpus N` over RCCL on a node with fewer than N devices exits non-zero and prints no line -- never a single-GPU
     number under an N-GPU label."""
