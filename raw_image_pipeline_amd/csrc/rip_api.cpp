@@ -965,7 +965,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
   // the caller's stream waits for the internal one before this function returns, so the batch is complete in stream order
   // exactly as without the split.  Measured on config2 (256 frames, one box, round 3): 4.87 ms per step unsplit; mode 1 with
   // 2 / 4 / 8 / 16 groups 4.98 / 5.00 / 5.09 / 5.70; mode 2 with 2 / 4 groups 4.94 / 5.05 -- the three kernels lean on the
-  // same VALU issue slots and LDS, and the shorter launches pay their tails (EXPERIMENTS.md, round 3), so the default stays 1.
+  // same VALU issue slots and LDS, and the shorter launches pay their tails (docs/experiments_r1-3.md), so the default stays 1.
   bool stats_cleared_here = false;
   const size_t stats_clean_before = (p->stats_clean_ptr == p->d_stats.ptr && p->stats_clean_cap == p->d_stats.cap) ? p->stats_clean_bytes : 0;
   int groups = 1;

@@ -210,7 +210,7 @@ __device__ __forceinline__ void fast_chunks(const ChainParams& p, const ItemMap&
 template <int BITS, int WB, int NT>
 __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_kernel(ChainParams p, ItemMap im, int items_per_frame) {
   __shared__ FastTabs<BITS> tb;
-  tb.template load<NT>(p.tabs, p.vig_image);
+  tb.template load<NT>(p.tabs, p.vig_image, p.hsv_gain);
   CcRegs cc = {};
   if constexpr ((BITS & ST_CC) != 0) cc.load(p);
   HsvRegs hr = {};
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_fast_ke
 template <int BITS, int WB, int NT>
 __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_color_kernel(ChainParams p, ItemMap im, int items_per_frame) {
   __shared__ FastTabs<BITS> tb;
-  tb.template load<NT>(p.tabs, p.vig_image);
+  tb.template load<NT>(p.tabs, p.vig_image, p.hsv_gain);
   CcRegs cc = {};
   if constexpr ((BITS & ST_CC) != 0) cc.load(p);
   HsvRegs hr = {};
@@ -364,7 +364,7 @@ __device__ __forceinline__ void unpack3(const Pack3& v, uint32_t (&px)[4]) {
 template <int BITS, int WB, int NT>
 __global__ __launch_bounds__(NT, fast_waves_per_simd<BITS>()) void chain_rot_kernel(ChainParams p, int tiles_x, int tiles_per_frame) {
   __shared__ FastTabs<BITS> tb;
-  tb.template load<NT>(p.tabs, p.vig_image);
+  tb.template load<NT>(p.tabs, p.vig_image, p.hsv_gain);
   CcRegs cc = {};
   if constexpr ((BITS & ST_CC) != 0) cc.load(p);
   HsvRegs hr = {};

@@ -23,8 +23,16 @@ struct alignas(RIP_GAMMA_FOLD ? 256 : 4) GammaTab {
   uint8_t lut[256];
   __device__ __forceinline__ unsigned lds_address() const { return (unsigned)reinterpret_cast<uintptr_t>(&lut[0]); }
 };
+// Round 6: everything of cv::multiply(hsv, gains) + HSV2RGB_f that depends on ONE 8-bit channel alone is tabulated per launch
+// (the gains are launch constants): hs[s] = float(sat_u8(float(s) gain_s)) (1 / 255), hv[v] likewise, hw[h] = the three sector
+// weights w_b, w_g, w_r of the hue after its gain and wrap -- the same float operations apply_hsv_f spells out per pixel, done
+// once per table entry, so every pixel's bytes are unchanged (tests: test_color_enhancer*, the fuzz).  Per pixel that replaces
+// 3 int -> float conversions, up to 3 gain multiplies + saturating conversions + conversions back, 3 scale multiplies, 6
+// subtractions and 3 clamped min / max (18-24 VALU instructions of 66) by three LDS reads.
 struct HsvTab {
   int32_t sdiv[256], hdiv[256];
+  float hs[256], hv[256];
+  float4 hw[256];
 };
 template <int BITS>
 struct FastTabs {
@@ -43,7 +51,7 @@ struct FastTabs {
     return 0;
   }
   template <int NT>
-  __device__ __forceinline__ void load(const DevTables* t, const uint32_t* vig_image) {
+  __device__ __forceinline__ void load(const DevTables* t, const uint32_t* vig_image, const float* hsv_gain = nullptr) {
     if constexpr (kVig) {
       if (vig_image)
         vig.v.template load_image<NT>(vig_image);
@@ -56,6 +64,7 @@ struct FastTabs {
       for (int i = threadIdx.x; i < 256; i += NT) {
         hsv.v.sdiv[i] = t->sdiv[i];
         hsv.v.hdiv[i] = t->hdiv[i];
+        if (hsv_gain) hsv_tables_entry(hsv_gain, i, hsv.v.hs[i], hsv.v.hv[i], hsv.v.hw[i]);
       }
   }
 };
@@ -71,6 +80,28 @@ template <int BITS>
 constexpr int fast_waves_per_simd() {
   // vignetting + enhancer: 56 KB of tables, two workgroups per CU
   return (BITS & ST_VIG) ? ((BITS & ST_HSV) ? 4 : kVigWavesPerSimd) : 1;
+}
+
+// RGB2HSV_b (integer, as apply_hsv_f) + the tabulated rest of the colour enhancer (HsvTab)
+__device__ __forceinline__ void apply_hsv_tab(const HsvTab& t, int b, int g, int r, float (&out)[3]) {
+  const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+  const int diff = v - vmin;
+  const int s = (mul24(diff, t.sdiv[v]) + (1 << 11)) >> 12;
+  int h;
+  if (v == r)
+    h = g - b;
+  else if (v == g)
+    h = b - r + 2 * diff;
+  else
+    h = r - g + 4 * diff;
+  h = (mul24(h, t.hdiv[diff]) + (1 << 11)) >> 12;
+  h += h < 0 ? 180 : 0;  // [0, 179]: apply_hsv_f
+  const float fs = t.hs[s], fv = t.hv[v];
+  const float4 w = t.hw[h];
+  // contracted model: 1 - s * w is one fnma (apply_hsv_f)
+  out[0] = (fv * mul_add(-fs, w.x, 1.f)) * 255.f;
+  out[1] = (fv * mul_add(-fs, w.y, 1.f)) * 255.f;
+  out[2] = (fv * mul_add(-fs, w.z, 1.f)) * 255.f;
 }
 
 // The per-pixel stages after the demosaic for the four pixels of one row; returns the 12 interleaved output bytes.
@@ -136,16 +167,8 @@ __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb&
   }
   if constexpr ((BITS & ST_HSV) != 0) {
     float of[4][3];
-    if (hr.unit == 5u) {  // hue and value gains are 1 (the usual configuration scales the saturation only)
-      keep_branch();
 #pragma unroll
-      for (int k = 0; k < 4; k++) apply_hsv_f<5u>(hr.g, tb, q[k][0], q[k][1], q[k][2], of[k]);
-    } else {
-      asm volatile("s_nop 0 ; rip_generic_hsv_gains");  // marks the block for tools/chain_ledger.py (bench runs take the other one)
-#pragma unroll
-      for (int k = 0; k < 4; k++) apply_hsv_f<0u>(hr.g, tb, q[k][0], q[k][1], q[k][2], of[k]);
-      asm volatile("s_nop 0 ; rip_generic_hsv_end");
-    }
+    for (int k = 0; k < 4; k++) apply_hsv_tab(tb.hsv.v, q[k][0], q[k][1], q[k][2], of[k]);
     return pack4_from_floats(of);
   }
   return pack4(q);

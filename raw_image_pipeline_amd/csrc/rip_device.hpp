@@ -679,6 +679,16 @@ __device__ __forceinline__ void apply_hsv_f(const float (&hg)[3], const Tabs& tb
   out[1] = og * 255.f;
   out[2] = orr * 255.f;
 }
+// One entry (index i = the 8-bit h / s / v BEFORE its gain) of the per-launch tables of the fast kernels (rip_chain_dev.hpp HsvTab):
+// exactly the operations apply_hsv_f<0> applies to a pixel whose channel has the value i.
+__device__ __forceinline__ void hsv_tables_entry(const float* hg, int i, float& hs, float& hv, float4& hw) {
+  const float fi = (float)i;
+  hs = (float)sat_round_u8(fi * hg[1]) * (1.f / 255.f);
+  hv = (float)sat_round_u8(fi * hg[2]) * (1.f / 255.f);
+  float fh = (float)sat_round_u8(fi * hg[0]) * (6.f / 180.f);
+  fh = fh >= 6.f ? fh - 6.f : fh;
+  hw = make_float4(max_sat(3.f - fh, fh - 5.f), max_sat(1.f - fh, fh - 3.f), min_sat(fh - 1.f, 5.f - fh), 0.f);
+}
 template <unsigned UNIT = 0u, typename Tabs>
 __device__ __forceinline__ void apply_hsv(const float (&hg)[3], const Tabs& tb, int& b, int& g, int& r) {
   float o[3];

@@ -63,6 +63,13 @@ case $exp in
     for nt in -1 0; do for mode in 1 2; do
       echo "== RIP_CHAIN_NT=$nt overlap_mode=$mode"; RIP_CHAIN_NT=$nt RIP_OVERLAP_MODE=$mode python tools/probes/remap_exp_probe.py --rounds 2 --steps 4 --tunable overlap_groups=0,8,16,22,32,43,64 2>&1 | grep "^mask"
     done; done | tee $out/mall.log ;;
+  hsv_tab)       # the enhancer's per-channel work tabulated (config 3): parity, then HEAD's library beside the tree's in one process
+    python -m pytest tests -m gpu -x -q -k "enhancer or hsv or config3 or fuzz or taps or colour or color" 2>&1 | tail -4 | tee $out/pytest.log
+    python tools/probes/remap_exp_probe.py --workload config3 --size 1920x1200 --libs head=$V/head.so,new= --rounds 3 2>&1 | grep "^mask" | tee $out/ab.log ;;
+  chain_deal)    # runs of chunks dealt round-robin to the XCDs in the fused chain (compile-time variants), one process
+    for wl in default_chain chain; do
+      python tools/probes/remap_exp_probe.py --workload $wl --libs base=,d1=$V/deal1.so,d3=$V/deal3.so,d5=$V/deal5.so,d10=$V/deal10.so,d24=$V/deal24.so --rounds 3 2>&1 | grep "^mask" | sed "s/^/$wl /"
+    done | tee $out/ab.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
