@@ -21,6 +21,7 @@ remap).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -414,6 +415,39 @@ def memory_rate_variant(args):
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
+def remap_components(args):
+    """roofline.per_kernel.remap.components: the ring remap with one part dropped at a time --
+    timing-only builds of the same kernel (raw_image_pipeline_amd/variants/exp.so: -DRIP_EXPERIMENTS, wrong pixels), all in ONE
+    process on one output allocation (tools/probes/remap_exp_probe.py), ms per launch of args.batch frames.  The parts do not
+    add up to the whole and do not hide behind each other either: loads alone + stores alone ~ the complete kernel -- the memory
+    system serves this kernel's read and write streams one after the other (EXPERIMENTS.md round 6)."""
+    exp = os.path.join(ROOT, "raw_image_pipeline_amd", "variants", "exp.so")
+    probe = os.path.join(ROOT, "tools", "probes", "remap_exp_probe.py")
+    if not (os.path.exists(exp) and os.path.exists(probe)):
+        return None
+    names = {0: "complete", 8: "without_gather_reads_and_arithmetic", 16: "without_stores", 32: "without_source_loads",
+             24: "source_loads_only", 40: "stores_only", 64: "without_plan_words"}
+    try:
+        r = subprocess.run([sys.executable, probe, "--masks", ",".join(str(m) for m in names), "--rounds", "2", "--steps", "4", "--batch", str(args.batch)],
+                           env=dict(os.environ, RIP_LIBRARY=exp), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
+    except Exception:
+        return None
+    out = {}
+    for l in r.stdout.splitlines():
+        if not l.startswith("mask"):
+            continue
+        try:
+            m = int(l.split()[1])
+            ms = json.loads(l[l.index("{"):].replace("'", '"'))
+            out[names[m]] = ms.get("remap")
+        except Exception:
+            continue
+    if "complete" not in out:
+        return None
+    out["unit"] = "ms per launch of %d frames; timing-only builds of remap_ring_kernel (wrong pixels), one process, medians of 2 x 4 launches" % args.batch
+    return out
+
+
 def baseline_metric():
     """BASELINE.json's metric string, verbatim."""
     try:
@@ -735,6 +769,9 @@ def main():
             roofline["traffic_source"] += "; live PMC pass unavailable (%s)" % why
     if world == 1 and not args.no_pmc and args.workload == "config2":
         roofline["memory_rate_variant"] = memory_rate_variant(args)
+        comp = remap_components(args)
+        if comp is not None:
+            roofline.setdefault("per_kernel", {}).setdefault("remap", {})["components"] = comp
     if world == 1 and not args.no_hbm_probe:
         # what this box's HBM actually delivers to a plain streaming kernel, beside the 8 TB/s spec
         del out

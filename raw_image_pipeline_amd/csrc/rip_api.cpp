@@ -1289,6 +1289,7 @@ Tunables tunables_from_env() {
   t.remap_frames = positive("RIP_REMAP_FRAMES", t.remap_frames);
   t.remap_exp = positive("RIP_REMAP_EXP", t.remap_exp);
   if (const char* e = std::getenv("RIP_REMAP_DEAL")) t.remap_deal = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("RIP_CHAIN_DEAL")) t.chain_deal = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("RIP_REMAP_FUSED")) t.remap_fused = std::atoi(e) != 0;
   if (const char* e = std::getenv("RIP_CHAIN_NT")) t.chain_nt = std::atoi(e);
   t.ccc_lds_hist_min = positive("RIP_CCC_LDS_HIST_MIN", t.ccc_lds_hist_min);
@@ -2165,6 +2166,7 @@ rip_status rip_set_tunable(rip_pipeline* p, const char* name, int value) {
     else if (n == "remap_fused") t.remap_fused = value;
     else if (n == "remap_exp") t.remap_exp = value;
     else if (n == "remap_deal") t.remap_deal = value;
+    else if (n == "chain_deal") t.chain_deal = value;
     else if (n == "chain_nt") t.chain_nt = value;
     else if (n == "remap_tiled") p->use_tiled_remap = value != 0;
     else if (n == "ccc_lds_hist_min") t.ccc_lds_hist_min = value > 0 ? value : dflt.ccc_lds_hist_min;

@@ -114,16 +114,16 @@ __device__ __forceinline__ void fast_chunks(const ChainParams& p, const ItemMap&
   const int xcd = blockIdx.x & 7;
   const int flip180 = p.flip_angle == 180 ? 1 : 0;
   const DemosaicSel ds = demosaic_selectors(p.bayer_ry, p.bayer_rx, flip180);
-#ifndef RIP_CHAIN_DEAL
-#define RIP_CHAIN_DEAL 0
-#endif
-  constexpr int kDeal = RIP_CHAIN_DEAL;  // experiment: runs of kDeal chunks dealt round-robin to the XCDs (0: one contiguous range each)
-  const int ci_end = kDeal > 0 ? ((chunks_per_frame + kDeal - 1) / kDeal + 7) / 8 * kDeal : per_xcd;
+  // Round 6: runs of p.deal chunks dealt round-robin to the XCDs -- the chunks in flight on the whole chip then form ONE band of
+  // the frame (as the ring remap's tiles do, rip_remap_dev.hpp TileDeal), which the memory system serves 3-5 % faster than eight
+  // bands; vertically adjacent row pairs, which share two halo rows, still meet in one L2 inside a run.  p.deal == 0: contiguous.
+  const int deal = p.deal;
+  const int ci_end = deal > 0 ? ((chunks_per_frame + deal - 1) / deal + 7) / 8 * deal : per_xcd;
   for (int ci = blockIdx.x >> 3; ci < ci_end; ci += gridDim.x >> 3) {
     int chunk = xcd * per_xcd + ci;
-    if (kDeal > 0) {
-      const int r = ci / kDeal;
-      chunk = (r * 8 + xcd) * kDeal + (ci - r * kDeal);
+    if (deal > 0) {
+      const int r = ci / deal;
+      chunk = (r * 8 + xcd) * deal + (ci - r * deal);
       if (chunk >= chunks_per_frame) continue;
     }
     if (chunk >= chunks_per_frame) break;
@@ -580,7 +580,9 @@ static int frame_groups(const ChainParams& p, const Tunables& tn, int cap, int b
   const bool valu_bound = (p.stage_bits & (ST_VIG | ST_HSV)) != 0;
   // memory-rate stage sets: two frames per visit (four once the colour matrix or the gamma table add per-pixel work) --
   // the per-item setup is shared and a workgroup lives a little longer, while the frames it touches stay few
-  const int streaming = (p.stage_bits & (ST_CC | ST_GAMMA)) ? 4 : 2;
+  // (round 6, with the round-robin deal of the chunks -- p.deal > 0 -- and 256 frames of 2448x2048, gains + colour matrix + gamma at
+  // 2 / 4 / 6 / 8 / 16 frames per visit: 1.461 / 1.240 / 1.213 / 1.247 / 1.286 ms)
+  const int streaming = (p.stage_bits & (ST_CC | ST_GAMMA)) ? (p.deal > 0 ? 6 : 4) : 2;
   const int frames_per_visit = tn.chain_frames > 0 ? tn.chain_frames : (valu_bound ? 16 : streaming);
   const int groups = std::max(cap / std::max(blocks, 1), (p.n_frames + frames_per_visit - 1) / frames_per_visit);
   return std::max(1, std::min(p.n_frames, groups));
@@ -607,7 +609,9 @@ void launch_debayer16(const Debayer16Params& p, hipStream_t stream) {
 
 #endif  // RIP_FP_CONTRACT
 
-void launch_chain(const ChainParams& p, const Tunables& tn, hipStream_t stream) {
+void launch_chain(const ChainParams& p_in, const Tunables& tn, hipStream_t stream) {
+  ChainParams p = p_in;
+  p.deal = tn.chain_deal;
   if (p.n_frames <= 0) return;
 #if !RIP_FP_CONTRACT
   if (p.fp_contract == 1) return launch_chain_fc1(p, tn, stream);

@@ -70,6 +70,17 @@ case $exp in
     for wl in default_chain chain; do
       python tools/probes/remap_exp_probe.py --workload $wl --libs base=,d1=$V/deal1.so,d3=$V/deal3.so,d5=$V/deal5.so,d10=$V/deal10.so,d24=$V/deal24.so --rounds 3 2>&1 | grep "^mask" | sed "s/^/$wl /"
     done | tee $out/ab.log ;;
+  chain_deal2)   # the runtime chain deal (default 3): parity, then frames per item visit under it
+    python -m pytest tests -m gpu -x -q -k "not submit and not rig and not ring and not bench" 2>&1 | tail -4 | tee $out/pytest.log
+    python tools/probes/remap_exp_probe.py --workload default_chain --rounds 2 --tunable chain_frames=2,4,6,8,16 2>&1 | grep "^mask" | sed "s/^/default_chain /" | tee $out/frames.log
+    python tools/probes/remap_exp_probe.py --workload chain --rounds 2 --tunable chain_frames=8,16,32 2>&1 | grep "^mask" | sed "s/^/chain /" | tee -a $out/frames.log
+    python tools/probes/remap_exp_probe.py --workload chain --rounds 2 --tunable chain_deal=0,1,2,3,4,6 2>&1 | grep "^mask" | sed "s/^/chain /" | tee -a $out/frames.log
+    python tools/probes/remap_exp_probe.py --workload default_chain --rounds 2 --tunable chain_deal=0,1,2,3,4,6 2>&1 | grep "^mask" | sed "s/^/default_chain /" | tee -a $out/frames.log ;;
+  chain_frames)  # frames per item visit of the VALU-bound stage sets under the deal, and the demosaic-only set
+    python tools/probes/remap_exp_probe.py --workload chain --rounds 3 --tunable chain_frames=12,16,24,32,64 2>&1 | grep "^mask" | sed "s/^/chain /" | tee $out/frames.log
+    python tools/probes/remap_exp_probe.py --workload config3 --size 1920x1200 --rounds 3 --tunable chain_frames=8,16,24,32,64 2>&1 | grep "^mask" | sed "s/^/config3 /" | tee -a $out/frames.log
+    python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable chain_frames=16,32 2>&1 | grep "^mask" | sed "s/^/config2 /" | tee -a $out/frames.log
+    python bench.py --no-cpu-baseline 2>&1 | tail -1 | tee $out/bench.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
