@@ -1096,7 +1096,9 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     // ---- chain + remap in one kernel (memory-rate stage sets, no taps) ---------------------------------
     if (fused) {
       ProfScope ps(p, RIP_KERNEL_REMAP, front);
-      if (!rip::launch_remap_fused(tiled_params(in_g, in_step, in_frame_stride, rows, cols, f0, ng), chain_params(in_g, wb_g, ng), p->plan.max_rect_w,
+      rip::ChainParams fc = chain_params(in_g, wb_g, ng);
+      fc.dst_streaming = (n >= 8 && p->tn.chain_nt != 0) ? 1 : 0;  // the kernel's output is the batch's final image: non-temporal stores for batches
+      if (!rip::launch_remap_fused(tiled_params(in_g, in_step, in_frame_stride, rows, cols, f0, ng), fc, p->plan.max_rect_w,
                                    p->plan.max_rect_h, p->tn, front, /*dry_run=*/false))
         throw DeviceError("internal: the fused remap refused a geometry it had accepted");
       continue;
@@ -1348,7 +1350,12 @@ rip_status rip_create(int device, int use_gpu, const char* params_path, const ch
     if (const char* e = std::getenv("RIP_PLAN_ON_HOST")) p->plan_on_host = *e && *e != '0';
     if (const char* e = std::getenv("RIP_DEBUG_DIR")) if (*e) p->debug_dir = e;
     if (const char* e = std::getenv("RIP_CCC_MODEL")) if (*e) p->ccc_model_env = e;
-    if (const char* e = std::getenv("RIP_FP_CONTRACT")) p->fp_contract = std::atoi(e) == 1 ? 1 : 0;
+    if (const char* e = std::getenv("RIP_FP_CONTRACT")) {
+      // the same values rip_set_fp_contraction accepts; anything else ("2", "true", a typo) fails the create instead of silently
+      // selecting the x86 model
+      if ((e[0] != '0' && e[0] != '1') || e[1] != 0) throw rip::YamlError(std::string("RIP_FP_CONTRACT=[") + e + "]: 0 (uncontracted) or 1 (contracted) expected");
+      p->fp_contract = e[0] == '1' ? 1 : 0;
+    }
     if (!p->ccc_model_env.empty()) rip::ccc_load_model_file(p->ccc, p->ccc_model_env);
     *out = p;
     return RIP_OK;

@@ -143,6 +143,8 @@ __device__ __forceinline__ Pack3 pointwise4(const ChainParams& p, const FrameWb&
       // colour matrix -> gamma table -> output (the reference's default stage set): saturate_cast<uchar> lands in byte 0 of the
       // table's LDS address, the twelve look-ups are merged like the Lab round trip's (ds_read_u8 / ds_read_u8_d16_hi pairs:
       // two ORs and one v_lshl_or_b32 per output dword instead of two shifts, a shift-or and a three-way or)
+      // the folded look-up needs byte 0 of the table's LDS address to be zero (v_cvt_pk_u8_f32 writes the index there)
+      static_assert(alignof(GammaTab) == 256 && alignof(FastTabs<BITS>) >= 256, "gamma fold: the table must sit on a 256-byte boundary");
       const unsigned base = tb.gam.v.lds_address();
       unsigned addr[4][3];
 #pragma unroll

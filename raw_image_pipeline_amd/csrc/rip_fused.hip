@@ -18,6 +18,8 @@
 #include "rip_chain_dev.hpp"
 #include "rip_remap_dev.hpp"
 
+#include <cstdio>
+
 namespace rip {
 namespace {
 
@@ -225,7 +227,9 @@ __global__ __launch_bounds__(kRemapTileThreads, RIP_FUSED_WAVES) void remap_baye
       }
       // non-temporal: the final image, nobody on the device reads it again (round 5: 3.134 -> 3.055 ms per 256 frames at 3840 x 2160;
       // the same bit on the two-kernel remap of config 2, which pulls three times the bytes through the L2s, costs it 14 %)
-      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, blend4_bgrx(t0, t1, b0, b1, wxb, wyy), true);
+      // Batches only (c.dst_streaming: >= 8 frames and the chain_nt tunable allows it, set by run_batch as for the chain): a single
+      // frame's latency call keeps the default policy
+      store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, blend4_bgrx(t0, t1, b0, b1, wxb, wyy), c.dst_streaming);
     };
     auto wait_landed = [&](int f) {  // the Bayer bytes of frame f are in LDS (this wave's part): frames issued after f may fly
       const int ahead = min(dist - 1, f_end - 1 - f);
@@ -383,7 +387,12 @@ bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max
   q.deal_run = remap_deal_run(p.tiles_x, p.tiles_y, tn);
   const unsigned bgr_off = (unsigned)q.stages * stage_bytes;
   const unsigned lds = ((bgr_off + 2u * bgr_bytes) + 15u) & ~15u;
-  if (lds > 60u * 1024u) return false;
+  if (lds > 60u * 1024u) {
+    // the two-kernel path takes over; RIP_DEBUG_OCC says so (the four-byte colour image of round 5 made this limit bind for more
+    // geometries: ADVICE round 5)
+    if (tn.debug_occupancy && !dry_run) std::fprintf(stderr, "rip: chain inside the remap's tiles refused: %u bytes of LDS per workgroup (limit 61440), two kernels instead\n", lds);
+    return false;
+  }
   if (dry_run) return true;
   const int ntiles = p.tiles_x * p.tiles_y;
   // persistent workgroups per CU of the grid -- not clamped to what the LDS lets reside (round 5, 28.6 KB per workgroup = five

@@ -10,11 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_no_inline_asm_reads_a_fresh_dot_result():
-    src = [os.path.join(ROOT, "raw_image_pipeline_amd", "csrc", f) for f in ("rip_remap.hip", "rip_stats.hip", "rip_chain.hip", "rip_ccc.hip", "rip_maps.hip")]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hazard_check.py")] + src, capture_output=True, text=True, timeout=900)
+    src = [os.path.join(ROOT, "raw_image_pipeline_amd", "csrc", f) for f in ("rip_remap.hip", "rip_stats.hip", "rip_chain.hip", "rip_ccc.hip", "rip_maps.hip", "rip_fused.hip")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hazard_check.py")] + src, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout + r.stderr
     for f in src:
         assert os.path.basename(f) + ": 0 finding(s)" in r.stdout, r.stdout
+    # the translation units compiled a second time under the contracted model ship in the library too
+    for f in ("rip_chain.hip", "rip_fused.hip"):
+        assert f + " (RIP_FP_CONTRACT=1): 0 finding(s)" in r.stdout, r.stdout
 
 
 def test_the_checker_sees_the_hazard_it_is_there_for(tmp_path):

@@ -82,14 +82,25 @@ def check_listing(path):
 def main():
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
+        # every object the library links: the sources under the default flags, and the translation units build.py compiles a
+        # second time under the contracted floating-point model (the *_fc1 kernels ship too)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raw_image_pipeline_amd"))
+        import build as B
+        jobs = []
         for src in sys.argv[1:]:
             src = os.path.abspath(src)
-            extra = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if src.endswith("rip_chain.hip") else []
-            subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-x", "hip", "-c", src, "-save-temps", "-o", "x.o"], cwd=tmp, check=True,
+            jobs.append((src, [], ""))
+            if os.path.basename(src) in B.FC1_SOURCES:
+                jobs.append((src, ["-DRIP_FP_CONTRACT=1"], " (RIP_FP_CONTRACT=1)"))
+        for n, (src, defs, tag) in enumerate(jobs):
+            sub = os.path.join(tmp, str(n))
+            os.makedirs(sub)
+            extra = B.PER_SOURCE_FLAGS.get(os.path.basename(src), [])
+            subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + defs + ["-x", "hip", "-c", src, "-save-temps", "-o", "x.o"], cwd=sub, check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            lst = [f for f in os.listdir(tmp) if f.endswith("gfx950.s") and os.path.splitext(os.path.basename(src))[0] in f]
-            f = check_listing(os.path.join(tmp, lst[0]))
-            print("%s: %d finding(s)" % (os.path.basename(src), len(f)))
+            lst = [f for f in os.listdir(sub) if f.endswith("gfx950.s") and os.path.splitext(os.path.basename(src))[0] in f]
+            f = check_listing(os.path.join(sub, lst[0]))
+            print("%s%s: %d finding(s)" % (os.path.basename(src), tag, len(f)))
             for line in f[:20]:
                 print("   " + line)
             bad += len(f)

@@ -81,6 +81,18 @@ case $exp in
     python tools/probes/remap_exp_probe.py --workload config3 --size 1920x1200 --rounds 3 --tunable chain_frames=8,16,24,32,64 2>&1 | grep "^mask" | sed "s/^/config3 /" | tee -a $out/frames.log
     python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable chain_frames=16,32 2>&1 | grep "^mask" | sed "s/^/config2 /" | tee -a $out/frames.log
     python bench.py --no-cpu-baseline 2>&1 | tail -1 | tee $out/bench.log ;;
+  step_ab)       # the whole config 2 step, round 5's library (variants/r5.so) beside the tree's, one process
+    python tools/probes/remap_exp_probe.py --workload config2 --libs r5=$V/r5.so,new= --rounds 4 2>&1 | grep "^mask" | tee $out/ab.log ;;
+  step_sweep)    # tunables inside the whole config 2 step (the chain behaves differently in front of the remap)
+    python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable chain_deal=0,1,2,3,4 2>&1 | grep "^mask" | tee $out/chain_deal.log
+    python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable remap_frames=4,6,8 2>&1 | grep "^mask" | tee $out/remap_frames.log
+    python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable remap_deal=0,1,2 2>&1 | grep "^mask" | tee $out/remap_deal.log ;;
+  all_ab)        # every bench workload, round 5's library beside the tree's, one process each
+    for w in config2:2448x2048 chain:2448x2048 default_chain:2448x2048 config3:1920x1200 config5:3840x2160 config2:1440x1080 config2:1920x1200 config2:3840x2160; do
+      python tools/probes/remap_exp_probe.py --workload ${w%%:*} --size ${w##*:} --libs r5=$V/r5.so,new= --rounds 3 2>&1 | grep "^mask" | sed "s/^/$w /"
+    done | tee $out/ab.log ;;
+  tile_shape)    # 128 x 8 tiles (whole 128-byte lines per row segment) against 64 x 16, complete / stores only / loads only, one process
+    python tools/probes/remap_exp_probe.py --workload config2 --libs t64x16=$V/exp.so,t128x8=$V/t128x8.so --masks 0,40,24 --rounds 3 2>&1 | grep "^mask" | tee $out/ab.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
