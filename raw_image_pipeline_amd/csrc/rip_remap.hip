@@ -370,6 +370,19 @@ __global__ __launch_bounds__(kRemapTileThreads) void remap_ring_kernel(RemapTile
         if (px.a == 0x12345678u && px.b == 0x9abcdef0u && px.c == 0x0fedcba9u) store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, px);
         return;
       }
+#ifdef RIP_EXPERIMENTS
+      if (ex & (2048 | 4096)) {  // cache-policy bits of the output stores under the round-robin deal: 2048 nt, 4096 sc1, both: nt sc1 (correct pixels)
+        const u32x3 u = {px.a, px.b, px.c};
+        const __amdgpu_buffer_rsrc_t rs = frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes);
+        if ((ex & (2048 | 4096)) == 2048)
+          __builtin_amdgcn_raw_buffer_store_b96(u, rs, (int)dst_off, 0, 2);
+        else if ((ex & (2048 | 4096)) == 4096)
+          __builtin_amdgcn_raw_buffer_store_b96(u, rs, (int)dst_off, 0, 16);
+        else
+          __builtin_amdgcn_raw_buffer_store_b96(u, rs, (int)dst_off, 0, 18);
+        return;
+      }
+#endif
       store12(frame_rsrc(b.dst + (size_t)f * b.dst_frame_stride, dst_bytes), dst_off, px);
     };
 

@@ -93,6 +93,18 @@ case $exp in
     done | tee $out/ab.log ;;
   tile_shape)    # 128 x 8 tiles (whole 128-byte lines per row segment) against 64 x 16, complete / stores only / loads only, one process
     python tools/probes/remap_exp_probe.py --workload config2 --libs t64x16=$V/exp.so,t128x8=$V/t128x8.so --masks 0,40,24 --rounds 3 2>&1 | grep "^mask" | tee $out/ab.log ;;
+  remap_store_bits) # cache-policy bits of the remap's output stores under the deal (round 5, contiguous deal: nt +14 %, sc1 +10 %)
+    RIP_LIBRARY=$V/exp.so python tools/probes/remap_exp_probe.py --masks 0,2048,4096,6144 --rounds 3 2>&1 | grep "^mask" | tee $out/masks.log ;;
+  deal_traffic)  # what the deals do to the L2-level traffic (FETCH_SIZE / WRITE_SIZE per launch), and the time beside it
+    for d in 0 1 2 4; do
+      RIP_REMAP_DEAL=$d python tools/collect_pmc.py $out/remap_deal$d config2 > /dev/null 2>&1
+      echo "== RIP_REMAP_DEAL=$d"; grep "remap_ring_kernel\|chain_fast" $out/remap_deal$d/pmc_summary.txt
+    done | tee $out/remap.log
+    for d in 0 3 6 12; do
+      RIP_CHAIN_DEAL=$d python tools/collect_pmc.py $out/chain_deal$d chain default_chain > /dev/null 2>&1
+      echo "== RIP_CHAIN_DEAL=$d"; grep "chain_fast" $out/chain_deal$d/pmc_summary.txt
+    done | tee $out/chain.log
+    rm -rf $out/*/pmc_*_fetch $out/*/pmc_*_write $out/*/pmc_*_rdsplit ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
