@@ -611,7 +611,7 @@ void launch_debayer16(const Debayer16Params& p, hipStream_t stream) {
 
 void launch_chain(const ChainParams& p_in, const Tunables& tn, hipStream_t stream) {
   ChainParams p = p_in;
-  p.deal = tn.chain_deal;
+  p.deal = 0;  // the fast path below sets it (chunks of its workgroup size)
   if (p.n_frames <= 0) return;
 #if !RIP_FP_CONTRACT
   if (p.fp_contract == 1) return launch_chain_fc1(p, tn, stream);
@@ -647,6 +647,7 @@ void launch_chain(const ChainParams& p_in, const Tunables& tn, hipStream_t strea
     const int dflt_blocks = nt == kBlock ? 4096 : (p.n_frames <= 2 ? 1536 : 4096);
     const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : dflt_blocks) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
+    p.deal = tn.chain_deal > 0 ? std::max(1, tn.chain_deal * 512 / nt) : 0;  // the same pixels per run for 256- and 512-thread variants
     dim3 grid(blocks, frame_groups(p, tn, cap, blocks));
     switch (p.stage_bits & 15) {
 #define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream, tn.debug_occupancy != 0); break;

@@ -179,6 +179,31 @@ def test_undistortion_batch_through_the_lds_ring(gpu_pipe, oracle, monkeypatch, 
         assert_images_equal(out[i], ref, "ring frame %d (fov %g, %d stages)" % (i, fov, stages))
 
 
+@pytest.mark.parametrize("size,n", [((448, 272), 7), ((1000, 752), 13), ((2448, 2048), 3), ((640, 482), 1)])
+def test_the_deals_of_tiles_and_chunks_to_the_xcds_do_not_change_a_byte(gpu_pipe, oracle, size, n):
+    """Round 6: the remap's tiles and the chain's chunks are dealt to the XCDs round-robin in runs (RIP_REMAP_DEAL /
+    RIP_CHAIN_DEAL) instead of one contiguous range each.  The deal decides WHICH workgroup takes a tile / chunk, never what
+    it computes: every run length -- contiguous (0), the defaults, run lengths that leave ragged last runs and XCD shares
+    without work (tile / chunk counts that are no multiples of 8 x run) -- gives the image of the default deal, and that one
+    equals the oracle's (full chain of config 2: statistics, fused chain with the Lab round trip, ring remap)."""
+    import torch
+    w, h = size
+    c = cfg(flip=True, flip_angle=180, wb=True, wb_method="grey_world", cc=True, gamma=True, gamma_k=0.8, vig=True, undistort=True,
+            cam=synth.camera_model(w, h))
+    configure(gpu_pipe, c)
+    frames = np.stack([synth.gen_frame(w, h, "bayer_rggb8", seed=900 + i, kind="scene") for i in range(n)])
+    dev = torch.from_numpy(frames).cuda()
+    base = gpu_pipe.apply_device(dev, "bayer_rggb8").cpu().numpy()
+    ref, _ = oracle_run(oracle, c, frames[n - 1], "bayer_rggb8")
+    assert_images_equal(base[n - 1], ref, "default deals vs oracle %s" % (size,))
+    for chain_deal, remap_deal, frames_per_visit in [(0, 0, 0), (1, 1, 1), (2, 2, 2), (5, 3, 5), (7, 1, 3), (64, 9, 0), (3, 0, 4), (0, 1, 16)]:
+        gpu_pipe.set_tunable("chain_deal", chain_deal)
+        gpu_pipe.set_tunable("remap_deal", remap_deal)
+        gpu_pipe.set_tunable("remap_frames", frames_per_visit)
+        got = gpu_pipe.apply_device(dev, "bayer_rggb8").cpu().numpy()
+        assert np.array_equal(got, base), "chain_deal %d remap_deal %d frames %d changes the image at %s" % (chain_deal, remap_deal, frames_per_visit, size)
+
+
 @pytest.mark.parametrize("size,balance,fov", [((2448, 2048), 0.0, 1.0), ((1920, 1200), 1.0, 0.8), ((450, 270), 0.5, 3.6), ((131, 97), 1.0, 0.6)])
 def test_remap_plan_compiled_on_the_device_equals_the_host_plan(rip_lib, oracle, monkeypatch, size, balance, fov):
     """The remap plan (tile rectangles, 4-byte plan words, border pixels) is compiled on the device, where the maps are

@@ -105,6 +105,11 @@ case $exp in
       echo "== RIP_CHAIN_DEAL=$d"; grep "chain_fast" $out/chain_deal$d/pmc_summary.txt
     done | tee $out/chain.log
     rm -rf $out/*/pmc_*_fetch $out/*/pmc_*_write $out/*/pmc_*_rdsplit ;;
+  deal_final)    # the final deal defaults: invariance test, then the run lengths once more in the step
+    python -m pytest tests -m gpu -x -q -k "deals_of_tiles or undist or fused or config2 or flip" 2>&1 | tail -4 | tee $out/pytest.log
+    python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable remap_deal=1,2,4,6 2>&1 | grep "^mask" | tee $out/remap_deal.log
+    python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable chain_deal=0,2,3,4 2>&1 | grep "^mask" | tee $out/chain_deal.log
+    python tools/probes/remap_exp_probe.py --workload default_chain --rounds 3 --tunable chain_deal=0,2,3,4,6 2>&1 | grep "^mask" | tee $out/chain_deal_default.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
