@@ -117,14 +117,20 @@ __device__ __forceinline__ void fast_chunks(const ChainParams& p, const ItemMap&
   // Round 6: runs of p.deal chunks dealt round-robin to the XCDs -- the chunks in flight on the whole chip then form ONE band of
   // the frame (as the ring remap's tiles do, rip_remap_dev.hpp TileDeal), which the memory system serves 3-5 % faster than eight
   // bands; vertically adjacent row pairs, which share two halo rows, still meet in one L2 inside a run.  p.deal == 0: contiguous.
-  const int deal = p.deal;
-  const int ci_end = deal > 0 ? ((chunks_per_frame + deal - 1) / deal + 7) / 8 * deal : per_xcd;
-  for (int ci = blockIdx.x >> 3; ci < ci_end; ci += gridDim.x >> 3) {
-    int chunk = xcd * per_xcd + ci;
-    if (deal > 0) {
-      const int r = ci / deal;
-      chunk = (r * 8 + xcd) * deal + (ci - r * deal);
-      if (chunk >= chunks_per_frame) continue;
+  // (the dealt chunk number grows with ci, so the first one past the frame ends the workgroup's walk in both deals)
+  // The run length is a compile-time constant (3 x 512 items in chunks of this variant; a run-time divisor costs the Lab variant
+  // of config 2 eleven extra waits in its frame loop and 1.5 % of its time: the scheduler's doing, found by diffing the
+  // listings); p.deal only switches the deal on (RIP_CHAIN_DEAL != 0) or back to contiguous ranges.
+  constexpr int kDeal = 3 * 512 / NT;
+  const bool dealt = p.deal != 0;
+  for (int ci = blockIdx.x >> 3;; ci += gridDim.x >> 3) {
+    int chunk;
+    if (dealt) {
+      const int r = ci / kDeal;
+      chunk = (r * 8 + xcd) * kDeal + (ci - r * kDeal);
+    } else {
+      if (ci >= per_xcd) break;
+      chunk = xcd * per_xcd + ci;
     }
     if (chunk >= chunks_per_frame) break;
     const int item = chunk * NT + threadIdx.x;
@@ -647,7 +653,7 @@ void launch_chain(const ChainParams& p_in, const Tunables& tn, hipStream_t strea
     const int dflt_blocks = nt == kBlock ? 4096 : (p.n_frames <= 2 ? 1536 : 4096);
     const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : dflt_blocks) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
-    p.deal = tn.chain_deal > 0 ? std::max(1, tn.chain_deal * 512 / nt) : 0;  // the same pixels per run for 256- and 512-thread variants
+    p.deal = tn.chain_deal > 0 ? 1 : 0;  // runs of 3 x 512 items (fast_chunks kDeal: the same pixels per run for 256- and 512-thread variants)
     dim3 grid(blocks, frame_groups(p, tn, cap, blocks));
     switch (p.stage_bits & 15) {
 #define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream, tn.debug_occupancy != 0); break;

@@ -110,6 +110,9 @@ case $exp in
     python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable remap_deal=1,2,4,6 2>&1 | grep "^mask" | tee $out/remap_deal.log
     python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable chain_deal=0,2,3,4 2>&1 | grep "^mask" | tee $out/chain_deal.log
     python tools/probes/remap_exp_probe.py --workload default_chain --rounds 3 --tunable chain_deal=0,2,3,4,6 2>&1 | grep "^mask" | tee $out/chain_deal_default.log ;;
+  step_order)    # is the chain slower in the step with the new library, or is it the handle's allocation?  new first, r5 second, new with chain_deal 0 third
+    python tools/probes/remap_exp_probe.py --workload config2 --libs new=,r5=$V/r5.so,new0= --set new0:chain_deal=0 --rounds 4 2>&1 | grep "^mask" | tee $out/ab.log
+    python tools/probes/remap_exp_probe.py --workload config2 --libs r5=$V/r5.so,new0=,new= --set new0:chain_deal=0 --rounds 4 2>&1 | grep "^mask" | tee -a $out/ab.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
