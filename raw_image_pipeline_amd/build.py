@@ -14,7 +14,7 @@ HEADERS = ["rip_kernels.hpp", "rip_device.hpp", "rip_chain_dev.hpp", "rip_remap_
 # per-source additions.  rip_chain.hip: LLVM's max-ILP machine scheduler -- the fused chain is bound by VALU issue and LDS at
 # six waves per SIMD and gains 2.3 % from the extra instruction-level parallelism inside a wave (2.311 -> 2.257 ms per 256
 # frames); the same strategy costs the memory-bound remap 3.5 % and the ccc kernels 8 %, so it is not a global flag.
-PER_SOURCE_FLAGS = {"rip_chain.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+PER_SOURCE_FLAGS = {"rip_chain.hip": ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("RIP_CHAIN_SCHED", "max-ilp")] if os.environ.get("RIP_CHAIN_SCHED", "max-ilp") != "default" else []}  # RIP_CHAIN_SCHED: A/B builds of other strategies (tools/ab_chain.py)
 # translation units compiled a second time under the contracted floating-point model (rip_device.hpp RIP_FP_CONTRACT; object
 # <name>_fc1.o): the kernels rip_set_fp_contraction(1) selects.  -ffp-contract stays off: the fused forms are written out.
 FC1_SOURCES = ["rip_chain.hip", "rip_fused.hip"]

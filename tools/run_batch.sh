@@ -113,6 +113,15 @@ case $exp in
   step_order)    # is the chain slower in the step with the new library, or is it the handle's allocation?  new first, r5 second, new with chain_deal 0 third
     python tools/probes/remap_exp_probe.py --workload config2 --libs new=,r5=$V/r5.so,new0= --set new0:chain_deal=0 --rounds 4 2>&1 | grep "^mask" | tee $out/ab.log
     python tools/probes/remap_exp_probe.py --workload config2 --libs r5=$V/r5.so,new0=,new= --set new0:chain_deal=0 --rounds 4 2>&1 | grep "^mask" | tee -a $out/ab.log ;;
+  chain_sched)   # LLVM machine-scheduler strategies for rip_chain.hip (RIP_CHAIN_SCHED builds), one process, the chain writing the shared output
+    L=base=,ilp=$V/sched_iterative-ilp.so,minreg=$V/sched_iterative-minreg.so,maxocc=$V/sched_iterative-maxocc.so,memcl=$V/sched_max-memory-clause.so,dflt=$V/sched_default.so
+    for wl in chain default_chain config2; do python tools/probes/remap_exp_probe.py --workload $wl --libs $L --rounds 4 2>&1 | grep "^mask" | sed "s/^/$wl /"; done | tee $out/ab.log
+    python tools/probes/remap_exp_probe.py --workload config3 --size 1920x1200 --libs $L --rounds 4 2>&1 | grep "^mask" | sed "s/^/config3 /" | tee -a $out/ab.log ;;
+  chain_sched2)  # max-ilp (the tree) against iterative-ilp once more, both orders, the chain writing the shared output
+    for i in 1 2; do
+      python tools/probes/remap_exp_probe.py --workload chain --libs ilp=$V/sched_iterative-ilp.so,base= --rounds 5 2>&1 | grep "^mask"
+      python tools/probes/remap_exp_probe.py --workload chain --libs base=,ilp=$V/sched_iterative-ilp.so --rounds 5 2>&1 | grep "^mask"
+    done | tee $out/ab.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
