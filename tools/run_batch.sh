@@ -122,6 +122,9 @@ case $exp in
       python tools/probes/remap_exp_probe.py --workload chain --libs ilp=$V/sched_iterative-ilp.so,base= --rounds 5 2>&1 | grep "^mask"
       python tools/probes/remap_exp_probe.py --workload chain --libs base=,ilp=$V/sched_iterative-ilp.so --rounds 5 2>&1 | grep "^mask"
     done | tee $out/ab.log ;;
+  deal_check)    # the final remap deal (4 tile rows) on the other geometries and on config 5's fused kernel
+    python tools/probes/remap_exp_probe.py --workload config5 --size 3840x2160 --rounds 3 --tunable remap_deal=0,1,2,4,8 2>&1 | grep "^mask" | sed "s/^/config5 /" | tee $out/ab.log
+    for size in 1440x1080 1920x1200 3840x2160; do python tools/probes/remap_exp_probe.py --workload config2 --size $size --rounds 3 --tunable remap_deal=0,1,4 2>&1 | grep "^mask" | sed "s/^/config2:$size /"; done | tee -a $out/ab.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
