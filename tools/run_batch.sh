@@ -125,6 +125,13 @@ case $exp in
   deal_check)    # the final remap deal (4 tile rows) on the other geometries and on config 5's fused kernel
     python tools/probes/remap_exp_probe.py --workload config5 --size 3840x2160 --rounds 3 --tunable remap_deal=0,1,2,4,8 2>&1 | grep "^mask" | sed "s/^/config5 /" | tee $out/ab.log
     for size in 1440x1080 1920x1200 3840x2160; do python tools/probes/remap_exp_probe.py --workload config2 --size $size --rounds 3 --tunable remap_deal=0,1,4 2>&1 | grep "^mask" | sed "s/^/config2:$size /"; done | tee -a $out/ab.log ;;
+  act_model)     # is the remap bound by DRAM row activations?  row-segment patterns against tile-linear ones, one stream at a time and both
+    RIP_LIBRARY=$V/exp.so python tools/probes/remap_exp_probe.py --masks 24,28,40,42,8,14,78 --rounds 3 2>&1 | grep "^mask" | tee $out/masks.log ;;
+  survey)        # every reachable path (tools/path_survey.py), round 5's library and the tree's; latency probe
+    RIP_LIBRARY=$PWD/$V/r5.so python tools/path_survey.py 2>&1 | tee $out/r5.log | tail -40
+    python tools/path_survey.py 2>&1 | tee $out/new.log | tail -40
+    python tools/latency_probe.py 2>&1 | tee $out/latency.log | tail -12
+    RIP_LIBRARY=$PWD/$V/r5.so python tools/latency_probe.py 2>&1 | tee $out/latency_r5.log | tail -12 ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
