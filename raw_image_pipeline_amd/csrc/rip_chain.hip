@@ -653,7 +653,7 @@ void launch_chain(const ChainParams& p_in, const Tunables& tn, hipStream_t strea
     const int dflt_blocks = nt == kBlock ? 4096 : (p.n_frames <= 2 ? 1536 : 4096);
     const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : dflt_blocks) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
-    p.deal = tn.chain_deal > 0 ? 1 : 0;  // runs of 3 x 512 items (fast_chunks kDeal: the same pixels per run for 256- and 512-thread variants)
+    p.deal = tn.chain_deal > 0 && p.n_frames >= 4 ? 1 : 0;  // batches only (a single frame keeps the halo rows of neighbouring chunks in one L2);  // runs of 3 x 512 items (fast_chunks kDeal: the same pixels per run for 256- and 512-thread variants)
     dim3 grid(blocks, frame_groups(p, tn, cap, blocks));
     switch (p.stage_bits & 15) {
 #define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream, tn.debug_occupancy != 0); break;

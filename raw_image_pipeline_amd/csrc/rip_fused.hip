@@ -384,7 +384,7 @@ bool launch_remap_fused(const RemapTiledParams& p, const ChainParams& c, int max
   const unsigned bgr_bytes = ((((unsigned)max_rect_w + 6u) * 4u + kFusedRowPad) * ((unsigned)max_rect_h + 2u) + 32u + 15u) & ~15u;  // four bytes per pixel + 8 per row (kernel: bp)
   RemapTiledParams q = p;
   q.stages = std::max(2, std::min(4, tn.remap_stages));
-  q.deal_run = remap_deal_run(p.tiles_x, p.tiles_y, tn);
+  q.deal_run = b.n_frames >= 4 ? remap_deal_run(p.tiles_x, p.tiles_y, tn) : 0;  // batches only (rip_remap.hip)
   const unsigned bgr_off = (unsigned)q.stages * stage_bytes;
   const unsigned lds = ((bgr_off + 2u * bgr_bytes) + 15u) & ~15u;
   if (lds > 60u * 1024u) {

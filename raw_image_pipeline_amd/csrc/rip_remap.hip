@@ -478,7 +478,9 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
     const unsigned stage_bytes = (unsigned)pre * kRemapTileThreads * 16u;
     q.stages = std::max(2, std::min(4, stages_env));
     q.exp = tn.remap_exp;
-    q.deal_run = remap_deal_run(p.tiles_x, p.tiles_y, tn);
+    // batches only: a single frame (latency calls: 63.5 against 64.9 us for the reference's example configuration) gains nothing
+    // from one band across the chip and loses the neighbouring rectangles' meeting in one L2
+    q.deal_run = b.n_frames >= 4 ? remap_deal_run(p.tiles_x, p.tiles_y, tn) : 0;
     const unsigned lds = (unsigned)q.stages * stage_bytes + 16u;  // the three-dword tap reads run up to 11 B past a row
     const int per_cu = std::max(1, std::min(tn.remap_per_cu > 0 ? tn.remap_per_cu : 6, (int)((160u * 1024u) / (lds + 256u))));
     int blocks = std::min(256 * per_cu, (ntiles + 7) / 8 * 8);
@@ -498,7 +500,7 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
       // 4 / 6 / 8 / 10 / 12 / 16 frames per visit: 2448x2048 1.881 / 1.883 / 1.933 / 2.016 / 2.062 / 2.127 (another box: 2.091 /
       // 1.955 / 1.935 / 1.966 / 1.998 / 2.090); 3840x2160 2.879 / 2.853 / 2.846 / 2.861 / 2.876 / 2.914; 1920x1200 0.806 / 0.744 /
       // 0.722 / 0.721 / 0.722 / 0.738; 1440x1080 0.567 / 0.514 / 0.509 / 0.507 / 0.509 / 0.521 -- about 96 MB of source frames, 6 .. 12
-      if (tn.remap_deal > 0)
+      if (tn.remap_deal > 0 && b.n_frames >= 4)
         frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(6, ((96ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
       else
         frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(4, ((64ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));

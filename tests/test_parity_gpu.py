@@ -179,7 +179,7 @@ def test_undistortion_batch_through_the_lds_ring(gpu_pipe, oracle, monkeypatch, 
         assert_images_equal(out[i], ref, "ring frame %d (fov %g, %d stages)" % (i, fov, stages))
 
 
-@pytest.mark.parametrize("size,n", [((448, 272), 7), ((1000, 752), 13), ((2448, 2048), 3), ((640, 482), 1)])
+@pytest.mark.parametrize("size,n", [((448, 272), 7), ((1000, 752), 13), ((2448, 2048), 4), ((640, 482), 1)])
 def test_the_deals_of_tiles_and_chunks_to_the_xcds_do_not_change_a_byte(gpu_pipe, oracle, size, n):
     """Round 6: the remap's tiles and the chain's chunks are dealt to the XCDs round-robin in runs (RIP_REMAP_DEAL /
     RIP_CHAIN_DEAL) instead of one contiguous range each.  The deal decides WHICH workgroup takes a tile / chunk, never what
