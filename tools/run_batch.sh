@@ -132,6 +132,9 @@ case $exp in
     python tools/path_survey.py 2>&1 | tee $out/new.log | tail -40
     python tools/latency_probe.py 2>&1 | tee $out/latency.log | tail -12
     RIP_LIBRARY=$PWD/$V/r5.so python tools/latency_probe.py 2>&1 | tee $out/latency_r5.log | tail -12 ;;
+  soak)          # 2 000-case fuzz soak against the oracle + the determinism stress (the deals, the enhancer tables and the new defaults under them)
+    RIP_FUZZ_CASES=${1:-2000} python -m pytest tests/test_fuzz_gpu.py -m gpu -x -q 2>&1 | tail -4 | tee $out/fuzz.log
+    python tools/probes/determinism_stress.py 2>&1 | tail -12 | tee $out/determinism.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
