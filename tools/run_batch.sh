@@ -135,6 +135,13 @@ case $exp in
   soak)          # 2 000-case fuzz soak against the oracle + the determinism stress (the deals, the enhancer tables and the new defaults under them)
     RIP_FUZZ_CASES=${1:-2000} python -m pytest tests/test_fuzz_gpu.py -m gpu -x -q 2>&1 | tail -4 | tee $out/fuzz.log
     python tools/probes/determinism_stress.py 2>&1 | tail -12 | tee $out/determinism.log ;;
+  write_pattern) # the remap's write pattern alone (tools/probes/write_pattern_probe.hip): pattern or kernel structure?
+    B=tools/probes/bin/write_pattern_probe
+    { $B 64 16 6 4; $B 64 16 1 4; $B 64 16 16 4; $B 64 16 6 0; $B 64 16 12 4; $B 128 8 6 4; $B 256 4 6 4; } 2>&1 | tee $out/probe.log ;;
+  write_stride)  # does the distance between the frames of a visit matter to the write pattern?  (frame stride 15 040 512 = 2^15 x 459)
+    B=tools/probes/bin/write_pattern_probe
+    for pad in 0 256 1024 4096 8192 12288 32768 65536 69632 1048576 2101248; do $B 64 16 6 4 256 $pad 3 | grep -v "mode 0"; done 2>&1 | tee $out/probe.log
+    for f in 2 3 4; do $B 64 16 $f 4 256 0 3 | grep -v "mode 0"; done 2>&1 | tee -a $out/probe.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
