@@ -34,12 +34,45 @@ struct P {
   uint8_t* dst;
   int tw, th, tiles_x, tiles_y, fpv, run, frames, cadence, persistent, frame_major;
   size_t frame_stride;  // bytes between frames (kFrameBytes + pad)
+  unsigned* sync;       // [frames][8 shards x 32 dwords]: workgroups done with a frame, per XCD share; null = no frame lock
+  int lead;             // a workgroup starts frame f only when every workgroup has finished frame f - lead (bounded spin: a hint, not a dependency)
 };
 
 __device__ __forceinline__ int dealt(int ti, int xcd, int run, int ntiles) {
   const int r = ti / run;
   const int t = (r * 8 + xcd) * run + (ti - r * run);
   return t < ntiles ? t : -1;
+}
+
+// persistent grid, static ownership of tiles, the frame loop outermost, and a LOOSE frame lock: per frame and XCD share a counter of
+// finished workgroups; before frame f a workgroup waits (bounded) until all shares have finished frame f - lead
+__global__ __launch_bounds__(256) void locked_kernel(P p) {
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, share = gridDim.x >> 3;
+  const int per_xcd = ((ntiles + p.run - 1) / p.run + 7) / 8 * p.run;
+  const int lanes_per_row = p.tw / 4;
+  const int lrow = threadIdx.x / lanes_per_row, lcol = threadIdx.x % lanes_per_row;
+  for (int f = 0; f < p.frames; f++) {
+    if (f >= p.lead && threadIdx.x < 8) {
+      const unsigned* c = p.sync + ((size_t)(f - p.lead) * 8 + threadIdx.x) * 32;
+      for (int spin = 0; spin < 20000; spin++) {
+        const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_ballot_w64(v < (unsigned)share) == 0) break;  // lanes 0..7 active: all eight shares are through
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    for (int ti = wg; ti < per_xcd; ti += share) {
+      const int tile = dealt(ti, xcd, p.run, ntiles);
+      if (tile < 0) continue;
+      const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+      const int y = ty * p.th + lrow, x = tx * p.tw + lcol * 4;
+      if (y < kH && x < kW && lrow < p.th)
+        *reinterpret_cast<u32x3*>(p.dst + (size_t)f * p.frame_stride + (size_t)y * kPitch + (size_t)x * 3) = u32x3{(uint32_t)f, (uint32_t)tile, (uint32_t)threadIdx.x};
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(p.sync + ((size_t)f * 8 + xcd) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 __global__ __launch_bounds__(256) void tile_kernel(P p) {
@@ -118,6 +151,11 @@ static void launch(void* c) {
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<u32x4*>(x->p.dst), n16);
     return;
   }
+  if (x->mode >= 8) {
+    hipMemsetAsync(x->p.sync, 0, (size_t)x->p.frames * 8 * 32 * 4, 0);
+    hipLaunchKernelGGL(locked_kernel, dim3(x->mode >= 11 ? 1024 : 1536), dim3(256), 0, 0, x->p);
+    return;
+  }
   const int groups = (x->p.frames + x->p.fpv - 1) / x->p.fpv;
   hipLaunchKernelGGL(tile_kernel, dim3(1536, x->p.persistent ? 1 : groups), dim3(256), 0, 0, x->p);
 }
@@ -147,15 +185,20 @@ int main(int argc, char** argv) {
                          "remap order, one workgroup per frame group, barrier + vmcnt(1) per frame",
                          "FRAME-MAJOR inside the workgroup (its 3-4 tiles per frame), one workgroup per frame group, back to back",
                          "FRAME-MAJOR inside the workgroup, one workgroup per frame group, barrier + vmcnt(1) per store",
-                         "FRAME-MAJOR inside the workgroup, persistent grid, back to back"};
+                         "FRAME-MAJOR inside the workgroup, persistent grid, back to back",
+                         "persistent, frames outermost, LOOSE FRAME LOCK (lead 1)", "persistent, frames outermost, loose frame lock (lead 2)",
+                         "persistent, frames outermost, loose frame lock (lead 4)", "persistent 1024 workgroups, loose frame lock (lead 1)",
+                         "persistent 1024 workgroups, loose frame lock (lead 2)"};
   printf("tile %d x %d px (%d-byte row segments), %d frames per visit, runs of %d tiles, %d frames, %.2f GB, frame stride + %zu B\n", tw, th, tw * 3, fpv, c.p.run, frames,
          c.bytes / 1e9, pad);
-  for (int mode = 0; mode < 8; mode++) {
-    if (only >= 0 && mode != only && mode != 0) continue;
+  hipMalloc(&c.p.sync, (size_t)frames * 8 * 32 * 4);
+  for (int mode = 0; mode < 13; mode++) {
+    if (only >= 0 && mode != only && mode != 0 && !(only == 8 && mode >= 8)) continue;
     c.mode = mode;
     c.p.persistent = mode == 1 || mode == 2 || mode == 7;
     c.p.cadence = mode == 2 || mode == 4 || mode == 6;
     c.p.frame_major = mode >= 5;
+    c.p.lead = mode == 8 || mode == 11 ? 1 : (mode == 9 || mode == 12 ? 2 : 4);
     const float ms = time_ms(0, 5, {}, launch, &c);
     printf("mode %d  %-78s %7.3f ms  %6.0f GB/s\n", mode, names[mode], ms, c.bytes / (ms * 1e-3) / 1e9);
   }

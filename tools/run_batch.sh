@@ -142,6 +142,11 @@ case $exp in
     B=tools/probes/bin/write_pattern_probe
     for pad in 0 256 1024 4096 8192 12288 32768 65536 69632 1048576 2101248; do $B 64 16 6 4 256 $pad 3 | grep -v "mode 0"; done 2>&1 | tee $out/probe.log
     for f in 2 3 4; do $B 64 16 $f 4 256 0 3 | grep -v "mode 0"; done 2>&1 | tee -a $out/probe.log ;;
+  write_lock)    # persistent workgroups held to one frame by a loose frame lock: does the write stream reach the one-frame rate?
+    tools/probes/bin/write_pattern_probe 64 16 1 4 256 0 8 2>&1 | tee $out/probe.log ;;
+  remap_locked)  # (needs tools/probes/remap_frame_locked_experiment.patch applied) the frame-locked persistent remap kernel: parity against the per-visit ring, then its time for several leads
+    timeout 600 python -m pytest tests -m gpu -x -q -k "frame_locked" 2>&1 | tail -6 | tee $out/pytest.log
+    timeout 300 python tools/probes/remap_exp_probe.py --workload config2 --rounds 3 --tunable remap_locked=${1:-0,1,2,3,4,8} 2>&1 | grep "^mask" | tee $out/lead.log ;;
   suite)         # whole GPU suite + smoke
     python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $out/pytest.log
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $out/smoke.log ;;
