@@ -496,14 +496,13 @@ bool launch_remap_tiled(const RemapTiledParams& p, const Tunables& tn, hipStream
     int frames_per_visit = tn.remap_frames;
     if (frames_per_visit <= 0) {
       const unsigned long long frame_bytes = (unsigned long long)b.src_step * (unsigned long long)b.rows;
-      // round 6, with the round-robin deal (remap_deal; the XCDs no longer drift apart over a long visit), ms per 256 frames at
-      // 4 / 6 / 8 / 10 / 12 / 16 frames per visit: 2448x2048 1.881 / 1.883 / 1.933 / 2.016 / 2.062 / 2.127 (another box: 2.091 /
-      // 1.955 / 1.935 / 1.966 / 1.998 / 2.090); 3840x2160 2.879 / 2.853 / 2.846 / 2.861 / 2.876 / 2.914; 1920x1200 0.806 / 0.744 /
-      // 0.722 / 0.721 / 0.722 / 0.738; 1440x1080 0.567 / 0.514 / 0.509 / 0.507 / 0.509 / 0.521 -- about 96 MB of source frames, 6 .. 12
-      if (tn.remap_deal > 0 && b.n_frames >= 4)
-        frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(6, ((96ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
-      else
-        frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(4, ((64ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
+      // round 6, with the round-robin deal (one tile row per run) longer visits paid at first (2448x2048 at 4 / 6 / 8 / 12 / 16 frames: 2.091 /
+      // 1.955 / 1.935 / 1.998 / 2.090); with runs of four tile rows, inside the config 2 step, the optimum is back at the 64 MB rule:
+      // 3 / 4 / 5 / 6 / 8 / 12 frames 1.920 / 1.860 / 1.874 / 1.902 / 1.999 / 2.135 (another box: . / . / 1.744 / 1.771 / 1.863 / .); 1440x1080 at
+      // 4 / 6 / 8 / 12: 0.569 / 0.533 / 0.526 / 0.533; 1920x1200 0.804 / 0.756 / 0.738 / 0.736; 3840x2160 3.077 / 3.054 / 3.066 / 3.149 -- the
+      // fewer frames the grid writes at once, the better for the write stream (tools/probes/write_pattern_probe.hip), the more the
+      // plan words and the per-visit start-up cost the read side
+      frames_per_visit = (int)std::min<unsigned long long>(12, std::max<unsigned long long>(4, ((64ull << 20) + frame_bytes / 2) / std::max<unsigned long long>(1, frame_bytes)));
     }
     int groups = std::max((256 * per_cu) / blocks, (b.n_frames + frames_per_visit - 1) / frames_per_visit);
     groups = std::max(1, std::min(b.n_frames, groups));
