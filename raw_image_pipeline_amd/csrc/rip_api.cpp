@@ -1126,6 +1126,7 @@ void run_batch(rip_pipeline* p, const Plan& pl, const uint8_t* d_in, size_t in_s
     c.dst_streaming = (n >= 8 && p->tn.chain_nt != 0 && (!pl.remap || p->tn.chain_nt < 0)) ? 1 : 0;
     c.tap = d_tap_deb ? d_tap_deb + (size_t)f0 * tap_frame : nullptr;
     c.tap_frame_stride = tap_frame;
+    c.deal = pl.remap ? -1 : 0;  // hint for launch_chain: the remap gathers from this image next (Tunables::chain_deal)
     // overlap_mode 2: only the statistics of this group share the chip with the remap of the previous one; the chain waits
     if (back != front && p->tn.overlap_mode == 2 && g > 0) HIP_CHECK(hipStreamWaitEvent(front, p->ovl_events[groups + g - 1], 0));
     {

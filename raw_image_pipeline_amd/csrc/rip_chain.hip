@@ -617,10 +617,11 @@ void launch_debayer16(const Debayer16Params& p, hipStream_t stream) {
 
 void launch_chain(const ChainParams& p_in, const Tunables& tn, hipStream_t stream) {
   ChainParams p = p_in;
-  p.deal = 0;  // the fast path below sets it (chunks of its workgroup size)
+  const bool remap_behind = p_in.deal < 0;  // run_batch's hint: the image this launch writes is the intermediate the remap gathers from
+  p.deal = 0;                               // the fast path below sets it
   if (p.n_frames <= 0) return;
 #if !RIP_FP_CONTRACT
-  if (p.fp_contract == 1) return launch_chain_fc1(p, tn, stream);
+  if (p.fp_contract == 1) return launch_chain_fc1(p_in, tn, stream);  // with run_batch's hint intact
 #endif
   if (chain_uses_rot_path(p)) {
     const int nt = (p.stage_bits & ST_VIG) ? fast_threads<ST_VIG>() : fast_threads<0>();
@@ -653,7 +654,11 @@ void launch_chain(const ChainParams& p_in, const Tunables& tn, hipStream_t strea
     const int dflt_blocks = nt == kBlock ? 4096 : (p.n_frames <= 2 ? 1536 : 4096);
     const int cap = std::max(8, grid_multiple_of_8(tn.chain_blocks > 0 ? tn.chain_blocks : dflt_blocks) * kBlock / nt / 8 * 8);
     int blocks = (int)std::min<long long>(cap, (chunks + 7) / 8 * 8);
-    p.deal = tn.chain_deal > 0 && p.n_frames >= 4 ? 1 : 0;  // batches only (a single frame keeps the halo rows of neighbouring chunks in one L2);  // runs of 3 x 512 items (fast_chunks kDeal: the same pixels per run for 256- and 512-thread variants)
+    // batches only (a single frame keeps the halo rows of neighbouring chunks in one L2), and by default not in front of the
+    // remap: there the deal buys nothing (config 2's chain inside the step, deal off -> on, three boxes: 2.193 -> 2.158, 2.215 ->
+    // 2.229, 2.169 -> 2.182 ms) while the input fetched at the L2s rises from 1.62 to 2.17 GB per 256 frames; alone the chain gains
+    // 3-6 %.  RIP_CHAIN_DEAL: 0 never, 1 when no remap follows, 2 always.  Runs of 3 x 512 items (fast_chunks kDeal)
+    p.deal = p.n_frames >= 4 && (tn.chain_deal >= 2 || (tn.chain_deal == 1 && !remap_behind)) ? 1 : 0;
     dim3 grid(blocks, frame_groups(p, tn, cap, blocks));
     switch (p.stage_bits & 15) {
 #define RIP_CASE(B) case B: launch_fast_wb<B>(p, im, items, grid, stream, tn.debug_occupancy != 0); break;

@@ -104,7 +104,7 @@ struct ChainParams {
   const uint32_t* vig_image;
   // floating-point contraction model of the float stages (rip_device.hpp RIP_FP_CONTRACT): 0 = none, 1 = fused as on FMA targets
   int fp_contract;
-  // set by the launchers (Tunables::chain_deal): 1 = the fast kernel deals its chunks round-robin to the XCDs (fast_chunks kDeal), 0 = one contiguous range per XCD
+  // in: -1 = the remap gathers from dst next (run_batch's hint); set by launch_chain (Tunables::chain_deal): 1 = the fast kernel deals its chunks round-robin to the XCDs (fast_chunks kDeal), 0 = one contiguous range per XCD
   int deal;
 };
 
@@ -235,7 +235,7 @@ struct Tunables {
   int remap_stages = 3;       // RIP_REMAP_STAGES: LDS ring size
   int remap_per_cu = 0;       // RIP_REMAP_PER_CU: resident workgroups per CU; 0 = 6 (ring) / 8 (tiled)
   int remap_frames = 0;       // RIP_REMAP_FRAMES: frames per tile visit (0: by the size of a source frame, 4 .. 12)
-  int chain_deal = 1;         // RIP_CHAIN_DEAL: != 0: the fast chain kernel deals runs of 3 x 512 items (of 4 x 2 pixels; 2.5 row pairs of a 2448-wide frame) round-robin to the XCDs, so that the whole chip reads and writes one band of the frame (round 6: default stage set 1.270 -> 1.204 ms, Lab chain alone 2.216 -> 2.158; runs of 1 .. 6 chunks run alike, 10 / 24 lose; the run length is a compile-time constant of the kernel); 0 = one contiguous range of chunks per XCD (rounds 1-5)
+  int chain_deal = 1;         // RIP_CHAIN_DEAL: the fast chain kernel deals runs of 3 x 512 items (of 4 x 2 pixels; 2.5 row pairs of a 2448-wide frame) round-robin to the XCDs, so that the whole chip reads and writes one band of the frame (round 6: default stage set 1.270 -> 1.204 ms, Lab chain alone 2.216 -> 2.158; runs of 1 .. 6 chunks run alike, 10 / 24 lose; the run length is a compile-time constant of the kernel) -- 1: when no remap gathers from the image afterwards (in front of the remap it gains nothing and fetches a third more input), 2: always, 0: one contiguous range of chunks per XCD (rounds 1-5)
   int remap_deal = 4;         // RIP_REMAP_DEAL: how the ring kernels deal the tiles to the eight XCDs -- k > 0: runs of about k tile rows round-robin (all XCDs work on one band of the image; round 6: -5 % at 4 frames per visit, -12 % with 6-8; 1, 2 and 4 tile rows run alike, 4 fetches least: 7.58 / 7.11 / 6.54 GB per 256 frames at the L2s), 0: one contiguous range of tiles per XCD (rounds 1-5)
   int remap_exp = 0;          // RIP_REMAP_EXP: bit mask of timing-only experiments (wrong pixels), honoured by -DRIP_EXPERIMENTS builds only (tools/probes/remap_exp_probe.py)
   int remap_fused = 1;        // RIP_REMAP_FUSED=0: never run the chain inside the remap's tiles (rip_fused.hip)
