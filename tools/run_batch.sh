@@ -2,6 +2,9 @@
 # One entry point for the GPU calls of a round: `gpurun -- bash tools/run_batch.sh <experiment> [args]`.
 # Results land under gpurun_out/r6_<experiment>/ (scratch); what is worth keeping is copied to profiles/ by hand.
 # Rounds 4-5 used one script per call (tools/batches/, kept for the record); round 6 on: one case per experiment here.
+# Library variants some cases name (raw_image_pipeline_amd/variants/, git-ignored) are built first with
+#   python tools/ab_chain.py build exp=-DRIP_EXPERIMENTS [name=-DFLAG,...]      (the tree with extra flags)
+#   git worktree add /tmp/wt <commit> && (cd /tmp/wt && python -c "from raw_image_pipeline_amd import build as b; b.build(force=True, out='<repo>/raw_image_pipeline_amd/variants/r5.so', tag='_r5')")   (an older tree: r5.so = round 5's 9e7d5bb, head.so)
 set -u
 exp=${1:?experiment name}; shift
 out=gpurun_out/r6_$exp; mkdir -p $out
